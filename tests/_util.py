@@ -1,0 +1,34 @@
+"""Shared helpers for the tests: golden loading and the parity gate."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def sub_state(g, prefix):
+    """state_dict (torch tensors) of the keys that start with ``prefix``."""
+    return {k[len(prefix):]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith(prefix)}
+
+
+def parity_gate(out, ref, rel=1e-4, what=""):
+    """SURVEY §8(d) gate for fp32: max|out-ref| <= rel*max|ref| and allclose(rtol=rel, atol=rel/10*max|ref|)."""
+    out = torch.as_tensor(out).double().cpu()
+    ref = torch.as_tensor(ref).double().cpu()
+    assert out.shape == ref.shape, f"{what}: shape {tuple(out.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    scale = ref.abs().max().item()
+    err = (out - ref).abs().max().item()
+    assert err <= rel * max(scale, 1e-30), f"{what}: max abs err {err:.3e} > {rel:g} * max|ref| ({scale:.3e})"
+    assert torch.allclose(out, ref, rtol=rel, atol=rel * 0.1 * scale), f"{what}: allclose(rtol={rel}) failed"
+    return err / max(scale, 1e-30)
+
+
+def gather_flat(t, idx):
+    return torch.as_tensor(t).reshape(-1)[torch.as_tensor(idx)]

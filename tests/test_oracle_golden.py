@@ -1,0 +1,122 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors captured from the imported reference.
+
+These fixtures were produced by tests/golden/make_golden.py running the
+reference's own ``unit_agcn`` / ``Unit2D`` / ``Graph`` on CPU.  The oracle is a
+restatement with different op ordering (einsum vs conv), so agreement is to
+fp32 rounding, gated at 2e-5 of max|ref| (the product's gate is 1e-4).
+"""
+import numpy as np
+import pytest
+import torch
+
+from _util import gather_flat, load_golden, parity_gate, sub_state
+from oracle import graph_oracle as go
+from oracle import stgcn_oracle as so
+
+TIGHT = 2e-5
+
+GCN_CASES = ["gcn_shre_3_128_quirk", "gcn_shre_3_128_trueA", "gcn_shre_3_128_default_init",
+             "gcn_lmdhg_3_128", "gcn_shre_64_64_identity", "gcn_shre_64_128"]
+TCN_CASES = ["tcn_128_128_k9", "tcn_64_128_k9_s2", "tcn_64_128_k1_s2", "tcn_128_128_k9_v46",
+             "tcn_32_64_k5_nobias"]
+STEM_CASES = ["stem_shre_T180", "stem_lmdhg_T200", "stem_shre_T500"]
+
+
+def test_graphs_match_reference():
+    g = load_golden("graphs")
+    for key, ref in g.items():
+        name, mode = key.split("/")
+        mine = go.labeling(name, mode)
+        assert mine.shape == ref.shape, key
+        np.testing.assert_allclose(mine, ref, rtol=0, atol=1e-15, err_msg=key)
+
+
+def test_spatial_graph_properties():
+    for name, V, nb in (("SHRE", 22, 21), ("LMDHG", 46, 50)):
+        A = go.labeling(name, "spatial")
+        assert A.shape == (3, V, V)
+        assert np.count_nonzero(A[0]) == V and np.count_nonzero(A[1]) == nb and np.count_nonzero(A[2]) == nb
+        # column-normalised: non-empty columns sum to one
+        for k in (1, 2):
+            cs = A[k].sum(0)
+            assert np.all((np.abs(cs - 1) < 1e-12) | (cs == 0))
+
+
+def test_aliasing_quirk_recorded():
+    """unit_agcn.__init__ overwrites the caller's A with 1e-6 (model/unit_agcn.py:37-39)."""
+    g = load_golden("gcn_shre_3_128_quirk")
+    assert np.all(g["A_after_ctor"] == np.float32(1e-6))
+    assert g["A_true"].sum() == pytest.approx(64.0, abs=1e-4) or g["A_true"].sum() > 22
+
+
+@pytest.mark.parametrize("case", GCN_CASES)
+@pytest.mark.parametrize("train", [False, True])
+def test_agcn_oracle_vs_reference(case, train):
+    g = load_golden(case)
+    p = so.agcn_params_from_state(sub_state(g, "gcn."), torch.from_numpy(g["A_fixed"]))
+    x = torch.from_numpy(g["x"])
+    aux = {}
+    y = so.agcn_forward(x, p, training=train, aux=aux)
+    tag = "train" if train else "eval"
+    parity_gate(aux["P"], g[f"P_{tag}"], TIGHT, f"{case} P {tag}")
+    parity_gate(y, g[f"y_{tag}"], TIGHT, f"{case} y {tag}")
+    if train:
+        parity_gate(aux["bn"]["running_mean"], g["after_train.gcn.bn.running_mean"], TIGHT, "bn rm")
+        parity_gate(aux["bn"]["running_var"], g["after_train.gcn.bn.running_var"], TIGHT, "bn rv")
+        if p.down_w is not None:
+            parity_gate(aux["down_bn"]["running_mean"], g["after_train.gcn.down.1.running_mean"], TIGHT, "dbn rm")
+            parity_gate(aux["down_bn"]["running_var"], g["after_train.gcn.down.1.running_var"], TIGHT, "dbn rv")
+
+
+def test_agcn_oracle_T180_samples():
+    g = load_golden("gcn_shre_3_128_T180")
+    p = so.agcn_params_from_state(sub_state(g, "gcn."), torch.from_numpy(g["A_fixed"]))
+    x = torch.from_numpy(g["x"])
+    for train in (False, True):
+        tag = "train" if train else "eval"
+        aux = {}
+        y = so.agcn_forward(x, p, training=train, aux=aux)
+        parity_gate(aux["P"], g[f"P_{tag}"], TIGHT, "P")
+        assert y.abs().max().item() == pytest.approx(float(g[f"y_{tag}_absmax"]), rel=1e-5)
+        err = (gather_flat(y, g[f"y_{tag}_idx"]).double() - torch.from_numpy(g[f"y_{tag}_val"]).double()).abs().max()
+        assert err <= TIGHT * float(g[f"y_{tag}_absmax"])
+
+
+@pytest.mark.parametrize("case", TCN_CASES)
+@pytest.mark.parametrize("train", [False, True])
+def test_tcn_oracle_vs_reference(case, train):
+    g = load_golden(case)
+    p = so.tcn_params_from_state(sub_state(g, "tcn."), stride=int(g["stride"]))
+    aux = {}
+    y = so.tcn_forward(torch.from_numpy(g["x"]), p, training=train, aux=aux)
+    parity_gate(y, g["y_train" if train else "y_eval"], TIGHT, case)
+    if train:
+        parity_gate(aux["bn"]["running_mean"], g["after_train.tcn.bn.running_mean"], TIGHT, "rm")
+        parity_gate(aux["bn"]["running_var"], g["after_train.tcn.bn.running_var"], TIGHT, "rv")
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_stem_oracle_vs_reference(case):
+    g = load_golden(case)
+    gp = so.agcn_params_from_state(sub_state(g, "gcn."), torch.from_numpy(g["A_fixed"]))
+    tp = so.tcn_params_from_state(sub_state(g, "tcn."))
+    x = so.caller_layout(torch.from_numpy(g["skeleton"]))
+    for train in (False, True):
+        tag = "train" if train else "eval"
+        aux = {}
+        z = so.stem_forward(x, gp, tp, training=train, aux=aux)
+        parity_gate(aux["gcn"]["P"], g[f"P_{tag}"], TIGHT, "P")
+        for nm, arr in (("y", aux["gcn_out"]), ("z", z)):
+            scale = float(g[f"{nm}_{tag}_absmax"])
+            err = (gather_flat(arr, g[f"{nm}_{tag}_idx"]).double()
+                   - torch.from_numpy(g[f"{nm}_{tag}_val"]).double()).abs().max().item()
+            assert err <= TIGHT * scale, f"{case} {nm} {tag}: {err:.3e} vs scale {scale:.3e}"
+            assert float(arr.double().sum()) == pytest.approx(float(g[f"{nm}_{tag}_sum"]), rel=1e-4, abs=1e-2 * scale)
+
+
+def test_float64_oracle_close_to_float32_reference():
+    """The fp64 run of the oracle is the tighter yardstick used by the GPU tests."""
+    g = load_golden("tcn_128_128_k9")
+    p = so.tcn_params_from_state(sub_state(g, "tcn.")).to(torch.float64)
+    y = so.tcn_forward(torch.from_numpy(g["x"]).double(), p)
+    parity_gate(y, g["y_eval"], TIGHT, "fp64 oracle vs fp32 reference")

@@ -1,0 +1,144 @@
+/*
+ * stgcn_hip.h — C ABI of libstgcn_hip.so: the MI355X (gfx950) ST-GCN stem.
+ *
+ * The reference (zjtggssg/ST-GCN-AltFormer) is pure Python/PyTorch and has no FFI of
+ * its own; the boundary it offers for this path is two nn.Modules.  Each entry point
+ * below replaces the torch ops executed inside one of their forward() bodies, so that
+ * a re-implementation of those modules (st-gcn-altformer_amd/model/{unit_agcn,net}.py,
+ * bound with ctypes — see INTEGRATION.md) is a drop-in:
+ *
+ *   stgcn_agcn_attention / stgcn_agcn_forward   <- model/unit_agcn.py:73-93  (unit_agcn.forward)
+ *   stgcn_tcn_*                                 <- model/net.py:47-57        (Unit2D.forward, dim=2)
+ *   stgcn_stem_*                                <- model/AltFormer/ST_GCN_AltFormer.py:70-72
+ *                                                  (tcn0(gcn0(x)) fused, intermediate kept on chip)
+ *   stgcn_bn_fold                               <- eval-mode nn.BatchNorm2d at unit_agcn.py:54,60, net.py:40
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller (e.g. the PyTorch caching
+ *     allocator).  The library allocates nothing, frees nothing, keeps no global mutable
+ *     state and never synchronises: all work is enqueued on `stream` (a hipStream_t
+ *     passed as void*; NULL = the default stream).  Safe to call from several host
+ *     threads / devices concurrently (the caller selects the device, as PyTorch does).
+ *   - Tensors are dense row-major fp32 unless stated: x is (N, C, T, V) exactly as
+ *     unit_agcn.forward receives it.
+ *   - Return value: 0 on success, a negative stgcn_status otherwise; the message for the
+ *     calling thread is available from stgcn_last_error().  Nothing throws or exits.
+ *   - `flags`: low 4 bits select the arithmetic of the temporal-conv contraction
+ *     (stgcn_math); STGCN_OUT_BF16 stores the final activation as bf16.
+ */
+#ifndef STGCN_HIP_H
+#define STGCN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STGCN_ABI_VERSION 1
+
+typedef enum {
+    STGCN_OK = 0,
+    STGCN_ERR_ARG = -1,          /* null pointer / non-positive dimension */
+    STGCN_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels cover  */
+    STGCN_ERR_WORKSPACE = -3,    /* caller workspace too small            */
+    STGCN_ERR_HIP = -4           /* a HIP runtime call failed             */
+} stgcn_status;
+
+typedef enum {
+    STGCN_MATH_F32 = 0,      /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain (default)      */
+    STGCN_MATH_BF16X3 = 1,   /* fp32 split into bf16 hi+lo, 3 bf16 MFMAs, fp32 accumulate   */
+    STGCN_MATH_BF16 = 2,     /* operands rounded to bf16, fp32 accumulate                   */
+    STGCN_MATH_F32_VALU = 3  /* plain fp32 VALU kernels (any shape; on-device cross-check)  */
+} stgcn_math;
+
+#define STGCN_MATH_MASK 0xFu
+#define STGCN_OUT_BF16 0x10u
+
+int stgcn_version(void);
+const char *stgcn_last_error(void);
+
+/* ---- eval-mode BatchNorm folding -------------------------------------------------------
+ * scale[c] = weight[c] / sqrt(running_var[c] + eps)
+ * shift[c] = bias[c] + (conv_bias[c] - running_mean[c]) * scale[c]      (conv_bias may be NULL)
+ */
+int stgcn_bn_fold(const float *weight, const float *bias, const float *running_mean,
+                  const float *running_var, const float *conv_bias, float eps, float *scale,
+                  float *shift, int C, void *stream);
+
+/* ---- adaptive graph convolution (unit_agcn) -------------------------------------------
+ * A_eff (S,V,V) = self.A + self.PA (unit_agcn.py:75-76), any dense values.
+ * Wa,Wb (S,inter_c,Cin), ba,bb (S,inter_c)  : conv_a / conv_b 1x1 weights and biases
+ * Wd (S,Cout,Cin), bd (S,Cout)              : conv_d
+ * Wdown (Cout,Cin), bdown (Cout)            : down[0]; pass NULL for both when Cin == Cout
+ *                                             (the reference then adds x itself, :57-58)
+ * bn_scale/bn_shift, down_scale/down_shift  : folded eval BatchNorm of self.bn / down[1]
+ *
+ * stgcn_agcn_attention: P[n,s,v,w] = softmax_v( sum_{c,t} a[c,t,v] b[c,t,w] / (inter_c*T) ) + A_eff[s,v,w]
+ *                       (unit_agcn.py:81-85); P is (N,S,V,V).
+ * stgcn_agcn_forward  : the whole forward; P_ws (N,S,V,V) is caller workspace and holds P on return;
+ *                       y is (N,Cout,T,V).
+ */
+int stgcn_agcn_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
+                         const float *Wb, const float *bb, float *P, int N, int Cin, int T, int V,
+                         int inter_c, int subsets, void *stream);
+
+int stgcn_agcn_forward(const float *x, const float *A_eff, const float *Wa, const float *ba,
+                       const float *Wb, const float *bb, const float *Wd, const float *bd,
+                       const float *Wdown, const float *bdown, const float *bn_scale,
+                       const float *bn_shift, const float *down_scale, const float *down_shift,
+                       float *P_ws, float *y, int N, int Cin, int Cout, int T, int V, int inter_c,
+                       int subsets, void *stream);
+
+/* ---- temporal conv block (Unit2D, dim=2) -----------------------------------------------
+ * W (Cout,Cin,K) = conv.weight with the trailing 1 squeezed; pad = (K-1)/2; T_out = (T+2*pad-K)/stride+1.
+ * scale/shift = folded BN (shift includes the conv bias).  y is (N,Cout,T_out,V), fp32 or bf16
+ * (STGCN_OUT_BF16).
+ *
+ * The contraction reads W re-ordered into MFMA fragment order with `scale` multiplied in
+ * ("packed").  Pack once per weight update with stgcn_tcn_pack into a buffer of
+ * stgcn_tcn_packed_bytes() bytes, then call stgcn_tcn_forward_packed per batch; or call
+ * stgcn_tcn_forward, which packs into `ws` (>= stgcn_tcn_packed_bytes) on every call.
+ */
+size_t stgcn_tcn_packed_bytes(int Cin, int Cout, int K, unsigned flags);
+/* 1 when the matrix-core kernel of `flags` covers the shape, 0 when only STGCN_MATH_F32_VALU does */
+int stgcn_tcn_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
+int stgcn_tcn_pack(const float *W, const float *scale, void *Wp, int Cin, int Cout, int K,
+                   unsigned flags, void *stream);
+int stgcn_tcn_forward_packed(const float *x, const void *Wp, const float *shift, void *y, int N,
+                             int Cin, int Cout, int T, int V, int K, int stride, unsigned flags,
+                             void *stream);
+int stgcn_tcn_forward(const float *x, const float *W, const float *scale, const float *shift,
+                      void *y, int N, int Cin, int Cout, int T, int V, int K, int stride, void *ws,
+                      size_t ws_bytes, unsigned flags, void *stream);
+
+/* ---- fused stem: tcn0(gcn0(x)) ----------------------------------------------------------
+ * Same operands as the two calls above (the temporal conv has Cin = Cout = C, stride 1).
+ * The (N,C,T,V) activation between the two modules is produced tile by tile in LDS and never
+ * written to HBM.  `prep` holds the folded graph-conv weights and the packed temporal weights:
+ * fill it with stgcn_stem_prepare (stgcn_stem_prep_bytes bytes) once per weight update.
+ * P_ws (N,S,V,V) is workspace and holds the attention matrices on return.
+ */
+size_t stgcn_stem_prep_bytes(int Cin, int C, int K, int subsets, unsigned flags);
+/* 1 when the fused kernel covers the shape (else run stgcn_agcn_forward + stgcn_tcn_forward) */
+int stgcn_stem_supported(int Cin, int C, int T, int V, int K, int subsets, unsigned flags);
+int stgcn_stem_prepare(const float *Wd, const float *bd, const float *Wdown, const float *bdown,
+                       const float *bn_scale, const float *bn_shift, const float *down_scale,
+                       const float *down_shift, const float *Wt, const float *t_scale, void *prep,
+                       int Cin, int C, int K, int subsets, unsigned flags, void *stream);
+int stgcn_stem_forward_prepared(const float *x, const float *A_eff, const float *Wa,
+                                const float *ba, const float *Wb, const float *bb,
+                                const void *prep, const float *t_shift, float *P_ws, void *out,
+                                int N, int Cin, int C, int T, int V, int inter_c, int subsets,
+                                int K, unsigned flags, void *stream);
+
+/* Second half of stgcn_stem_forward_prepared alone: P (N,S,V,V) already holds the attention matrices
+ * (from stgcn_agcn_attention); launches only the fused graph-conv + temporal-conv kernel. */
+int stgcn_stem_tail_prepared(const float *x, const float *P, const void *prep, const float *t_shift,
+                             void *out, int N, int Cin, int C, int T, int V, int subsets, int K,
+                             unsigned flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STGCN_HIP_H */

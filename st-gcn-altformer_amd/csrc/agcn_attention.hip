@@ -1,0 +1,295 @@
+// K1 — adjacency attention of the adaptive graph conv (model/unit_agcn.py:81-85):
+//
+//   P[n,s,v,w] = softmax_v( sum_{c<inter_c,t<T} a_s[c,t,v] * b_s[c,t,w] / (inter_c*T) ) + A_eff[s,v,w]
+//   a_s = Wa_s x + ba_s,  b_s = Wb_s x + bb_s   (1x1 convs)
+//
+// Two kernels:
+//  * attention_folded_kernel (small Cin, the stem has Cin = 3).  With x~ = [x; 1] the Gram is a
+//    bilinear form  S_s[v,w] = sum_{k,l} M_s[k,l] * G[(k,v),(l,w)],  M_s = Wa~_s^T Wb~_s ((Cin+1)^2),
+//    G = X~^T X~ with X~ the T x (Cin*V+1) matrix of one clip (last column = 1).  G is shared by
+//    all subsets, so one workgroup per clip streams x once (coalesced), keeps a register tile of G
+//    per thread, and the 32-channel embeddings are never materialised.
+//  * attention_generic_kernel (any Cin): embeddings built chunk-by-chunk in LDS, one workgroup per
+//    (clip, subset).
+//
+// Both are HBM-read-bound in principle (x is read once: 4*Cin*T*V bytes per clip) and tiny next to
+// the temporal conv; P (N,S,V,V) is written once.
+#include "common.h"
+
+namespace stgcn {
+
+namespace {
+
+constexpr int TM = 5;  // register tile of G: TM rows x TN cols per thread
+constexpr int TN = 4;
+constexpr int MS_FLOATS = 128;  // LDS reserved for the S*(Cin+1)^2 bilinear matrices
+
+// Column soft-max of Sm[s][v][w] over v, then P = soft + A_eff.  One thread per (s,w) column.
+__device__ __forceinline__ void softmax_columns_store(float *Sm, const float *__restrict__ A_eff,
+                                                      float *__restrict__ Pn, int S, int V, int s0,
+                                                      int tid, int nthreads) {
+    for (int e = tid; e < S * V; e += nthreads) {
+        const int s = e / V, w = e - s * V;
+        float *col = Sm + (size_t)s * V * V + w;
+        float m = col[0];
+        for (int v = 1; v < V; ++v) m = fmaxf(m, col[v * V]);
+        float sum = 0.f;
+        for (int v = 0; v < V; ++v) {
+            const float ex = expf(col[v * V] - m);
+            col[v * V] = ex;
+            sum += ex;
+        }
+        const float *Ae = A_eff + (size_t)(s0 + s) * V * V + w;
+        float *Po = Pn + (size_t)s * V * V + w;
+        for (int v = 0; v < V; ++v) Po[v * V] = col[v * V] / sum + Ae[v * V];
+    }
+}
+
+template <int MAXIT>
+__global__ __launch_bounds__(256) void attention_folded_kernel(
+    const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
+    const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
+    float *__restrict__ P, int Cin, int T, int V, int inter_c, int S, int TC, int Rp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x;
+    const int C1 = Cin + 1;
+    const int R = Cin * V + 1;  // columns of X~ (last one is the constant 1)
+    float *Ms = smem;
+    float *U = smem + MS_FLOATS;  // Xs[TC][Rp] while accumulating, then Gs[R][R] + Sm[S][V][V]
+
+    // M_s[k][l] = sum_c Wa~_s[c][k] * Wb~_s[c][l]   (bias folded in as column Cin)
+    for (int e = tid; e < S * C1 * C1; e += 256) {
+        const int s = e / (C1 * C1), kl = e - s * C1 * C1;
+        const int k = kl / C1, l = kl - k * C1;
+        float acc = 0.f;
+        for (int c = 0; c < inter_c; ++c) {
+            const int row = s * inter_c + c;
+            const float wa = (k < Cin) ? Wa[row * Cin + k] : ba[row];
+            const float wb = (l < Cin) ? Wb[row * Cin + l] : bb[row];
+            acc = fmaf(wa, wb, acc);
+        }
+        Ms[e] = acc;
+    }
+
+    const int nTr = (R + TM - 1) / TM, nTc = (R + TN - 1) / TN;
+    const int ntiles = nTr * nTc;
+    int r0[MAXIT], c0[MAXIT];
+    float acc[MAXIT][TM][TN];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int t = tid + it * 256;
+        const int tt = (t < ntiles) ? t : 0;
+        r0[it] = (tt / nTc) * TM;
+        c0[it] = (tt % nTc) * TN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[it][i][j] = 0.f;
+    }
+
+    const float *xn = x + (size_t)n * Cin * T * V;
+    const int CV = Cin * V;
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int tc = min(TC, T - t0);
+        __syncthreads();  // previous chunk fully consumed
+        for (int e = tid; e < TC * Rp; e += 256) {
+            const int tt = e / Rp, r = e - tt * Rp;
+            float val = 0.f;
+            if (tt < tc) {
+                if (r < CV) {
+                    const int k = r / V, v = r - k * V;
+                    val = xn[((size_t)k * T + (t0 + tt)) * V + v];
+                } else if (r == CV) {
+                    val = 1.f;
+                }
+            }
+            U[e] = val;
+        }
+        __syncthreads();
+        for (int tt = 0; tt < tc; ++tt) {
+            const float *row = U + tt * Rp;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = row[r0[it] + i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = row[c0[it] + j];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[it][i][j] = fmaf(a[i], b[j], acc[it][i][j]);
+            }
+        }
+    }
+    __syncthreads();
+    float *Gs = U;           // [R][R]
+    float *Sm = U + R * R;   // [S][V][V]
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        if (tid + it * 256 < ntiles) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (r0[it] + i < R && c0[it] + j < R) Gs[(r0[it] + i) * R + c0[it] + j] = acc[it][i][j];
+        }
+    }
+    __syncthreads();
+    const float denom = (float)(inter_c * T);  // A1.size(-1) at unit_agcn.py:84
+    for (int e = tid; e < S * V * V; e += 256) {
+        const int s = e / (V * V), vw = e - s * V * V;
+        const int v = vw / V, w = vw - v * V;
+        const float *M = Ms + s * C1 * C1;
+        float sacc = 0.f;
+        for (int k = 0; k < C1; ++k) {
+            const int gr = (k < Cin) ? k * V + v : CV;
+            for (int l = 0; l < C1; ++l) {
+                const int gc = (l < Cin) ? l * V + w : CV;
+                sacc = fmaf(M[k * C1 + l], Gs[gr * R + gc], sacc);
+            }
+        }
+        Sm[e] = sacc / denom;
+    }
+    __syncthreads();
+    softmax_columns_store(Sm, A_eff, P + (size_t)n * S * V * V, S, V, 0, tid, 256);
+}
+
+// Generic Cin: one workgroup per (subset, clip).
+template <int MAXIT>
+__global__ __launch_bounds__(256) void attention_generic_kernel(
+    const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
+    const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
+    float *__restrict__ P, int Cin, int T, int V, int inter_c, int S, int TC) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x, n = blockIdx.y;
+    const int PXC = TC * V;
+    float *Xs = smem;                    // [Cin][PXC]
+    float *As = Xs + (size_t)Cin * PXC;  // [inter_c][PXC]
+    float *Bs = As + (size_t)inter_c * PXC;
+    const float *xn = x + (size_t)n * Cin * T * V;
+    const float *wa = Wa + (size_t)s * inter_c * Cin;
+    const float *wb = Wb + (size_t)s * inter_c * Cin;
+
+    float acc[MAXIT];
+    int pv[MAXIT], pw[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int e = tid + it * 256;
+        const int ee = (e < V * V) ? e : 0;
+        pv[it] = ee / V;
+        pw[it] = ee % V;
+        acc[it] = 0.f;
+    }
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int tc = min(TC, T - t0);
+        const int px = tc * V;
+        __syncthreads();
+        for (int e = tid; e < Cin * px; e += 256) {
+            const int k = e / px, p = e - k * px;
+            Xs[k * PXC + p] = xn[((size_t)k * T + t0) * V + p];
+        }
+        __syncthreads();
+        for (int e = tid; e < inter_c * px; e += 256) {
+            const int c = e / px, p = e - c * px;
+            float a = ba[s * inter_c + c], b = bb[s * inter_c + c];
+            for (int k = 0; k < Cin; ++k) {
+                const float xv = Xs[k * PXC + p];
+                a = fmaf(wa[c * Cin + k], xv, a);
+                b = fmaf(wb[c * Cin + k], xv, b);
+            }
+            As[c * PXC + p] = a;
+            Bs[c * PXC + p] = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            float a = acc[it];
+            for (int c = 0; c < inter_c; ++c)
+                for (int tt = 0; tt < tc; ++tt)
+                    a = fmaf(As[c * PXC + tt * V + pv[it]], Bs[c * PXC + tt * V + pw[it]], a);
+            acc[it] = a;
+        }
+    }
+    __syncthreads();
+    float *Sm = smem;  // [V][V]
+    const float denom = (float)(inter_c * T);
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int e = tid + it * 256;
+        if (e < V * V) Sm[e] = acc[it] / denom;
+    }
+    __syncthreads();
+    softmax_columns_store(Sm, A_eff, P + ((size_t)n * S + s) * V * V, 1, V, s, tid, 256);
+}
+
+}  // namespace
+
+int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
+                     const float *Wb, const float *bb, float *P, int N, int Cin, int T, int V,
+                     int inter_c, int S, hipStream_t st) {
+    const int C1 = Cin + 1;
+    const int R = Cin * V + 1;
+    const int nTr = ceil_div(R, TM), nTc = ceil_div(R, TN);
+    const int ntiles = nTr * nTc;
+    const size_t gs_floats = (size_t)R * R + (size_t)S * V * V;
+    const bool folded = Cin <= 4 && S * C1 * C1 <= MS_FLOATS && ntiles <= 8 * 256 &&
+                        (MS_FLOATS + gs_floats) * 4 <= 150 * 1024;
+    if (folded) {
+        int Rp = nTr * TM > nTc * TN ? nTr * TM : nTc * TN;
+        Rp |= 1;  // odd row stride spreads the per-thread tile reads over banks
+        // chunk of frames held in LDS: whole clip when it fits in ~64 KiB, else as many as do
+        size_t budget = (size_t)96 * 1024 / 4;
+        if (gs_floats > budget) budget = gs_floats;
+        int TC = (int)(budget / Rp);
+        if (TC > T) TC = T;
+        if (TC < 1) TC = 1;
+        size_t u_floats = (size_t)TC * Rp;
+        if (u_floats < gs_floats) u_floats = gs_floats;
+        const size_t lds = (MS_FLOATS + u_floats) * 4;
+        const int maxit = ceil_div(ntiles, 256);
+#define LAUNCH_FOLDED(MI)                                                                     \
+    do {                                                                                      \
+        STGCN_HIP_CHECK(allow_lds(attention_folded_kernel<MI>, lds));                         \
+        hipLaunchKernelGGL(attention_folded_kernel<MI>, dim3(N), dim3(256), lds, st, x, A_eff, \
+                           Wa, ba, Wb, bb, P, Cin, T, V, inter_c, S, TC, Rp);                 \
+    } while (0)
+        if (maxit <= 1) LAUNCH_FOLDED(1);
+        else if (maxit <= 2) LAUNCH_FOLDED(2);
+        else if (maxit <= 4) LAUNCH_FOLDED(4);
+        else LAUNCH_FOLDED(8);
+#undef LAUNCH_FOLDED
+        STGCN_LAUNCH_CHECK("attention_folded_kernel");
+        return STGCN_OK;
+    }
+    // generic path
+    const int maxit = ceil_div(V * V, 256);
+    if (maxit > 16) return fail(STGCN_ERR_UNSUPPORTED, "attention: V=%d too large (max 64)", V);
+    const size_t budget = (size_t)96 * 1024 / 4;
+    int TC = (int)(budget / ((size_t)V * (Cin + 2 * inter_c)));
+    if (TC > T) TC = T;
+    if (TC < 1) TC = 1;
+    size_t fl = (size_t)TC * V * (Cin + 2 * inter_c);
+    if (fl < (size_t)V * V) fl = (size_t)V * V;
+    const size_t lds = fl * 4;
+    if (lds > (size_t)kLdsBytes)
+        return fail(STGCN_ERR_UNSUPPORTED, "attention: Cin=%d inter_c=%d V=%d needs %zu B of LDS", Cin,
+                    inter_c, V, lds);
+#define LAUNCH_GENERIC(MI)                                                                       \
+    do {                                                                                         \
+        STGCN_HIP_CHECK(allow_lds(attention_generic_kernel<MI>, lds));                           \
+        hipLaunchKernelGGL(attention_generic_kernel<MI>, dim3(S, N), dim3(256), lds, st, x, A_eff, \
+                           Wa, ba, Wb, bb, P, Cin, T, V, inter_c, S, TC);                        \
+    } while (0)
+    if (maxit <= 2) LAUNCH_GENERIC(2);
+    else if (maxit <= 4) LAUNCH_GENERIC(4);
+    else if (maxit <= 9) LAUNCH_GENERIC(9);
+    else LAUNCH_GENERIC(16);
+#undef LAUNCH_GENERIC
+    STGCN_LAUNCH_CHECK("attention_generic_kernel");
+    return STGCN_OK;
+}
+
+}  // namespace stgcn

@@ -1,0 +1,189 @@
+// extern "C" surface of libstgcn_hip.so (declared in include/stgcn_hip.h): argument validation,
+// thread-local error text, and dispatch to the kernel launchers.  No allocation, no sync.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace stgcn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(stgcn_status st, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return (int)st;
+}
+
+namespace {
+
+__global__ void bn_fold_kernel(const float *__restrict__ w, const float *__restrict__ b,
+                               const float *__restrict__ rm, const float *__restrict__ rv,
+                               const float *__restrict__ cb, float eps, float *__restrict__ scale,
+                               float *__restrict__ shift, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    // same operation order as ATen's CPU batch-norm transform: w / sqrt(var + eps)
+    const float s = w[c] / sqrtf(rv[c] + eps);
+    const float centre = (cb ? cb[c] : 0.f) - rm[c];
+    scale[c] = s;
+    shift[c] = fmaf(centre, s, b[c]);
+}
+
+}  // namespace
+
+int launch_bn_fold(const float *w, const float *b, const float *rm, const float *rv, const float *cb,
+                   float eps, float *scale, float *shift, int C, hipStream_t st) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, w, b, rm, rv, cb, eps, scale,
+                       shift, C);
+    STGCN_LAUNCH_CHECK("bn_fold_kernel");
+    return STGCN_OK;
+}
+
+}  // namespace stgcn
+
+using namespace stgcn;
+
+#define REQUIRE_PTR(p)                                                              \
+    do {                                                                            \
+        if ((p) == nullptr) return fail(STGCN_ERR_ARG, "%s: %s is NULL", __func__, #p); \
+    } while (0)
+#define REQUIRE_POS(v)                                                                        \
+    do {                                                                                      \
+        if ((v) <= 0) return fail(STGCN_ERR_ARG, "%s: %s = %d must be positive", __func__, #v, (int)(v)); \
+    } while (0)
+
+extern "C" {
+
+int stgcn_version(void) { return STGCN_ABI_VERSION; }
+
+const char *stgcn_last_error(void) { return g_err; }
+
+int stgcn_bn_fold(const float *weight, const float *bias, const float *running_mean,
+                  const float *running_var, const float *conv_bias, float eps, float *scale, float *shift,
+                  int C, void *stream) {
+    REQUIRE_PTR(weight); REQUIRE_PTR(bias); REQUIRE_PTR(running_mean); REQUIRE_PTR(running_var);
+    REQUIRE_PTR(scale); REQUIRE_PTR(shift); REQUIRE_POS(C);
+    return launch_bn_fold(weight, bias, running_mean, running_var, conv_bias, eps, scale, shift, C,
+                          (hipStream_t)stream);
+}
+
+int stgcn_agcn_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
+                         const float *Wb, const float *bb, float *P, int N, int Cin, int T, int V,
+                         int inter_c, int subsets, void *stream) {
+    REQUIRE_PTR(x); REQUIRE_PTR(A_eff); REQUIRE_PTR(Wa); REQUIRE_PTR(ba); REQUIRE_PTR(Wb); REQUIRE_PTR(bb);
+    REQUIRE_PTR(P);
+    REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(inter_c); REQUIRE_POS(subsets);
+    if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "attention: N=%d > 65535 clips per call", N);
+    return launch_attention(x, A_eff, Wa, ba, Wb, bb, P, N, Cin, T, V, inter_c, subsets, (hipStream_t)stream);
+}
+
+int stgcn_agcn_forward(const float *x, const float *A_eff, const float *Wa, const float *ba,
+                       const float *Wb, const float *bb, const float *Wd, const float *bd,
+                       const float *Wdown, const float *bdown, const float *bn_scale,
+                       const float *bn_shift, const float *down_scale, const float *down_shift, float *P_ws,
+                       float *y, int N, int Cin, int Cout, int T, int V, int inter_c, int subsets,
+                       void *stream) {
+    REQUIRE_PTR(Wd); REQUIRE_PTR(bd); REQUIRE_PTR(bn_scale); REQUIRE_PTR(bn_shift); REQUIRE_PTR(y);
+    REQUIRE_POS(Cout);
+    if ((Wdown == nullptr) != (bdown == nullptr) || (Wdown == nullptr) != (down_scale == nullptr) ||
+        (Wdown == nullptr) != (down_shift == nullptr))
+        return fail(STGCN_ERR_ARG, "agcn_forward: Wdown/bdown/down_scale/down_shift must be all set or all NULL");
+    if (Wdown == nullptr && Cin != Cout)
+        return fail(STGCN_ERR_ARG, "agcn_forward: identity residual needs Cin == Cout (got %d, %d)", Cin, Cout);
+    int rc = stgcn_agcn_attention(x, A_eff, Wa, ba, Wb, bb, P_ws, N, Cin, T, V, inter_c, subsets, stream);
+    if (rc != STGCN_OK) return rc;
+    return launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, bn_scale, bn_shift, down_scale, down_shift, y, N,
+                              Cin, Cout, T, V, subsets, (hipStream_t)stream);
+}
+
+size_t stgcn_tcn_packed_bytes(int Cin, int Cout, int K, unsigned flags) {
+    if (Cin <= 0 || Cout <= 0 || K <= 0) return 0;
+    return tcn_packed_bytes(Cin, Cout, K, flags);
+}
+
+int stgcn_tcn_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags) {
+    if (Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || K <= 0 || stride <= 0) return 0;
+    return tcn_mfma_supported(Cin, Cout, T, V, K, stride, flags) ? 1 : 0;
+}
+
+int stgcn_stem_supported(int Cin, int C, int T, int V, int K, int subsets, unsigned flags) {
+    if (Cin <= 0 || C <= 0 || T <= 0 || V <= 0 || K <= 0 || subsets <= 0) return 0;
+    return stem_fused_supported(Cin, C, T, V, K, subsets, flags) ? 1 : 0;
+}
+
+int stgcn_tcn_pack(const float *W, const float *scale, void *Wp, int Cin, int Cout, int K, unsigned flags,
+                   void *stream) {
+    REQUIRE_PTR(W); REQUIRE_PTR(scale); REQUIRE_PTR(Wp);
+    REQUIRE_POS(Cin); REQUIRE_POS(Cout); REQUIRE_POS(K);
+    return launch_tcn_pack(W, scale, Wp, Cin, Cout, K, flags, (hipStream_t)stream);
+}
+
+int stgcn_tcn_forward_packed(const float *x, const void *Wp, const float *shift, void *y, int N, int Cin,
+                             int Cout, int T, int V, int K, int stride, unsigned flags, void *stream) {
+    REQUIRE_PTR(x); REQUIRE_PTR(Wp); REQUIRE_PTR(shift); REQUIRE_PTR(y);
+    REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(Cout); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(K);
+    REQUIRE_POS(stride);
+    return launch_tcn(x, Wp, shift, y, N, Cin, Cout, T, V, K, stride, flags, (hipStream_t)stream);
+}
+
+int stgcn_tcn_forward(const float *x, const float *W, const float *scale, const float *shift, void *y, int N,
+                      int Cin, int Cout, int T, int V, int K, int stride, void *ws, size_t ws_bytes,
+                      unsigned flags, void *stream) {
+    REQUIRE_PTR(ws);
+    REQUIRE_POS(Cin); REQUIRE_POS(Cout); REQUIRE_POS(K);
+    const size_t need = tcn_packed_bytes(Cin, Cout, K, flags);
+    if (ws_bytes < need)
+        return fail(STGCN_ERR_WORKSPACE, "tcn_forward: workspace %zu B < %zu B", ws_bytes, need);
+    int rc = stgcn_tcn_pack(W, scale, ws, Cin, Cout, K, flags, stream);
+    if (rc != STGCN_OK) return rc;
+    return stgcn_tcn_forward_packed(x, ws, shift, y, N, Cin, Cout, T, V, K, stride, flags, stream);
+}
+
+size_t stgcn_stem_prep_bytes(int Cin, int C, int K, int subsets, unsigned flags) {
+    if (Cin <= 0 || C <= 0 || K <= 0 || subsets <= 0) return 0;
+    return stem_prep_bytes(Cin, C, K, subsets, flags);
+}
+
+int stgcn_stem_prepare(const float *Wd, const float *bd, const float *Wdown, const float *bdown,
+                       const float *bn_scale, const float *bn_shift, const float *down_scale,
+                       const float *down_shift, const float *Wt, const float *t_scale, void *prep, int Cin,
+                       int C, int K, int subsets, unsigned flags, void *stream) {
+    REQUIRE_PTR(Wd); REQUIRE_PTR(bd); REQUIRE_PTR(Wdown); REQUIRE_PTR(bdown); REQUIRE_PTR(bn_scale);
+    REQUIRE_PTR(bn_shift); REQUIRE_PTR(down_scale); REQUIRE_PTR(down_shift); REQUIRE_PTR(Wt);
+    REQUIRE_PTR(t_scale); REQUIRE_PTR(prep);
+    REQUIRE_POS(Cin); REQUIRE_POS(C); REQUIRE_POS(K); REQUIRE_POS(subsets);
+    return launch_stem_prepare(Wd, bd, Wdown, bdown, bn_scale, bn_shift, down_scale, down_shift, Wt, t_scale,
+                               prep, Cin, C, K, subsets, flags, (hipStream_t)stream);
+}
+
+int stgcn_stem_forward_prepared(const float *x, const float *A_eff, const float *Wa, const float *ba,
+                                const float *Wb, const float *bb, const void *prep, const float *t_shift,
+                                float *P_ws, void *out, int N, int Cin, int C, int T, int V, int inter_c,
+                                int subsets, int K, unsigned flags, void *stream) {
+    REQUIRE_PTR(prep); REQUIRE_PTR(t_shift); REQUIRE_PTR(out);
+    REQUIRE_POS(C); REQUIRE_POS(K);
+    int rc = stgcn_agcn_attention(x, A_eff, Wa, ba, Wb, bb, P_ws, N, Cin, T, V, inter_c, subsets, stream);
+    if (rc != STGCN_OK) return rc;
+    return launch_stem(x, P_ws, prep, t_shift, out, N, Cin, C, T, V, subsets, K, flags, (hipStream_t)stream);
+}
+
+int stgcn_stem_tail_prepared(const float *x, const float *P, const void *prep, const float *t_shift, void *out,
+                             int N, int Cin, int C, int T, int V, int subsets, int K, unsigned flags,
+                             void *stream) {
+    REQUIRE_PTR(x); REQUIRE_PTR(P); REQUIRE_PTR(prep); REQUIRE_PTR(t_shift); REQUIRE_PTR(out);
+    REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(C); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(subsets);
+    REQUIRE_POS(K);
+    return launch_stem(x, P, prep, t_shift, out, N, Cin, C, T, V, subsets, K, flags, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// Shared host/device helpers for libstgcn_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/stgcn_hip.h"
+
+namespace stgcn {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kLdsBytes = 160 * 1024;  // LDS per CU (and max per workgroup) on gfx950
+
+// thread-local last-error text (stgcn_last_error)
+void set_error(const char *fmt, ...);
+int fail(stgcn_status st, const char *fmt, ...);
+
+#define STGCN_HIP_CHECK(expr)                                                              \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return stgcn::fail(STGCN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define STGCN_LAUNCH_CHECK(name)                                                           \
+    do {                                                                                   \
+        hipError_t _e = hipGetLastError();                                                 \
+        if (_e != hipSuccess)                                                              \
+            return stgcn::fail(STGCN_ERR_HIP, "launch of %s failed: %s", name,             \
+                               hipGetErrorString(_e));                                     \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// Opt a kernel in to more than 64 KiB of dynamic LDS.
+template <typename K>
+static inline hipError_t allow_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers implemented in the kernel translation units (all enqueue on `st`, return status)
+// ---------------------------------------------------------------------------------------
+int launch_bn_fold(const float *w, const float *b, const float *rm, const float *rv,
+                   const float *cb, float eps, float *scale, float *shift, int C, hipStream_t st);
+
+int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
+                     const float *Wb, const float *bb, float *P, int N, int Cin, int T, int V,
+                     int inter_c, int S, hipStream_t st);
+
+int launch_agcn_expand(const float *x, const float *P, const float *Wd, const float *bd,
+                       const float *Wdown, const float *bdown, const float *bn_scale,
+                       const float *bn_shift, const float *down_scale, const float *down_shift,
+                       float *y, int N, int Cin, int Cout, int T, int V, int S, hipStream_t st);
+
+// temporal conv
+size_t tcn_packed_bytes(int Cin, int Cout, int K, unsigned flags);
+int launch_tcn_pack(const float *W, const float *scale, void *Wp, int Cin, int Cout, int K,
+                    unsigned flags, hipStream_t st);
+int launch_tcn(const float *x, const void *Wp, const float *shift, void *y, int N, int Cin,
+               int Cout, int T, int V, int K, int stride, unsigned flags, hipStream_t st);
+
+bool tcn_mfma_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
+bool stem_fused_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags);
+
+// fused stem
+size_t stem_prep_bytes(int Cin, int C, int K, int S, unsigned flags);
+int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, const float *bdown,
+                        const float *bn_scale, const float *bn_shift, const float *down_scale,
+                        const float *down_shift, const float *Wt, const float *t_scale, void *prep,
+                        int Cin, int C, int K, int S, unsigned flags, hipStream_t st);
+int launch_stem(const float *x, const float *P, const void *prep, const float *t_shift, void *out,
+                int N, int Cin, int C, int T, int V, int S, int K, unsigned flags, hipStream_t st);
+
+}  // namespace stgcn

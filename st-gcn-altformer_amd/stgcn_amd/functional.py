@@ -1,0 +1,241 @@
+"""Tensor-level wrappers over the C ABI: torch supplies device memory and the stream, nothing else.
+
+Every function takes CUDA(HIP) tensors, validates dtype/contiguity/device, passes raw device
+pointers plus ``torch.cuda.current_stream()`` to libstgcn_hip.so and returns freshly allocated
+outputs.  Nothing here computes on the host and nothing falls back to torch ops.
+"""
+from __future__ import annotations
+
+from ctypes import c_float, c_int, c_size_t, c_uint, c_void_p
+from typing import Optional, Tuple
+
+import torch
+
+from . import _capi
+from ._capi import MATH_BF16, MATH_BF16X3, MATH_F32, MATH_F32_VALU, OUT_BF16  # noqa: F401 (re-export)
+
+BN_EPS = 1e-5
+
+
+def _dev_ptr(t: Optional[torch.Tensor], name: str, device=None, dtype=torch.float32) -> c_void_p:
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device}); this path has no CPU implementation")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name} is on {t.device}, expected {device}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def _stream(device) -> c_void_p:
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _flags(math: int, out_bf16: bool) -> int:
+    return (math & _capi.MATH_MASK) | (OUT_BF16 if out_bf16 else 0)
+
+
+def bn_fold(weight, bias, running_mean, running_var, conv_bias=None, eps: float = BN_EPS):
+    """Eval-mode BatchNorm as per-channel (scale, shift); see stgcn_bn_fold."""
+    dev = weight.device
+    C = weight.numel()
+    scale = torch.empty(C, device=dev, dtype=torch.float32)
+    shift = torch.empty(C, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_bn_fold", _dev_ptr(weight, "weight", dev), _dev_ptr(bias, "bias", dev),
+                   _dev_ptr(running_mean, "running_mean", dev), _dev_ptr(running_var, "running_var", dev),
+                   _dev_ptr(conv_bias, "conv_bias", dev), c_float(eps), _dev_ptr(scale, "scale"),
+                   _dev_ptr(shift, "shift"), c_int(C), _stream(dev))
+    return scale, shift
+
+
+def agcn_attention(x, A_eff, Wa, ba, Wb, bb) -> torch.Tensor:
+    """P (N,S,V,V) of unit_agcn.py:81-85.  Wa/Wb (S,inter_c,Cin), ba/bb (S,inter_c), A_eff (S,V,V)."""
+    dev = x.device
+    N, Cin, T, V = x.shape
+    S, inter_c, _ = Wa.shape
+    P = torch.empty(N, S, V, V, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_agcn_attention", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev),
+                   _dev_ptr(Wa, "Wa", dev), _dev_ptr(ba, "ba", dev), _dev_ptr(Wb, "Wb", dev),
+                   _dev_ptr(bb, "bb", dev), _dev_ptr(P, "P"), c_int(N), c_int(Cin), c_int(T), c_int(V),
+                   c_int(inter_c), c_int(S), _stream(dev))
+    return P
+
+
+def agcn_forward(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn_scale, bn_shift, down_scale,
+                 down_shift) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eval forward of unit_agcn.  Returns (y (N,Cout,T,V), P (N,S,V,V)).
+
+    Wd (S,Cout,Cin), bd (S,Cout); Wdown (Cout,Cin)/bdown/down_scale/down_shift or all None for
+    the identity residual (Cin == Cout).
+    """
+    dev = x.device
+    N, Cin, T, V = x.shape
+    S, inter_c, _ = Wa.shape
+    Cout = Wd.shape[1]
+    y = torch.empty(N, Cout, T, V, device=dev, dtype=torch.float32)
+    P = torch.empty(N, S, V, V, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_agcn_forward", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev),
+                   _dev_ptr(Wa, "Wa", dev), _dev_ptr(ba, "ba", dev), _dev_ptr(Wb, "Wb", dev),
+                   _dev_ptr(bb, "bb", dev), _dev_ptr(Wd, "Wd", dev), _dev_ptr(bd, "bd", dev),
+                   _dev_ptr(Wdown, "Wdown", dev), _dev_ptr(bdown, "bdown", dev),
+                   _dev_ptr(bn_scale, "bn_scale", dev), _dev_ptr(bn_shift, "bn_shift", dev),
+                   _dev_ptr(down_scale, "down_scale", dev), _dev_ptr(down_shift, "down_shift", dev),
+                   _dev_ptr(P, "P"), _dev_ptr(y, "y"), c_int(N), c_int(Cin), c_int(Cout), c_int(T), c_int(V),
+                   c_int(inter_c), c_int(S), _stream(dev))
+    return y, P
+
+
+def tcn_supported(Cin, Cout, T, V, K, stride, math=MATH_F32) -> bool:
+    return bool(_capi.lib().stgcn_tcn_supported(Cin, Cout, T, V, K, stride, _flags(math, False)))
+
+
+def tcn_out_frames(T: int, K: int, stride: int) -> int:
+    pad = int((K - 1) / 2)
+    return (T + 2 * pad - K) // stride + 1
+
+
+def tcn_pack(W, scale, math=MATH_F32) -> torch.Tensor:
+    """Pack conv.weight (Cout,Cin,K) * scale into the kernel's operand order; returns a byte buffer."""
+    dev = W.device
+    Cout, Cin, K = W.shape
+    fl = _flags(math, False)
+    nbytes = _capi.lib().stgcn_tcn_packed_bytes(Cin, Cout, K, fl)
+    Wp = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_tcn_pack", _dev_ptr(W, "W", dev), _dev_ptr(scale, "scale", dev),
+                   c_void_p(Wp.data_ptr()), c_int(Cin), c_int(Cout), c_int(K), c_uint(fl), _stream(dev))
+    return Wp
+
+
+def tcn_forward_packed(x, Wp, shift, Cout, K, stride=1, math=MATH_F32, out_bf16=False) -> torch.Tensor:
+    dev = x.device
+    N, Cin, T, V = x.shape
+    Tout = tcn_out_frames(T, K, stride)
+    if Tout < 1:
+        raise ValueError(f"temporal conv: T={T}, K={K}, stride={stride} leaves no output frame")
+    y = torch.empty(N, Cout, Tout, V, device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_tcn_forward_packed", _dev_ptr(x, "x", dev), c_void_p(Wp.data_ptr()),
+                   _dev_ptr(shift, "shift", dev), c_void_p(y.data_ptr()), c_int(N), c_int(Cin), c_int(Cout),
+                   c_int(T), c_int(V), c_int(K), c_int(stride), c_uint(_flags(math, out_bf16)), _stream(dev))
+    return y
+
+
+def tcn_forward(x, W, scale, shift, stride=1, math=MATH_F32, out_bf16=False) -> torch.Tensor:
+    """One-shot temporal conv block: packs into a scratch buffer, then runs (stgcn_tcn_forward)."""
+    dev = x.device
+    N, Cin, T, V = x.shape
+    Cout, _, K = W.shape
+    Tout = tcn_out_frames(T, K, stride)
+    if Tout < 1:
+        raise ValueError(f"temporal conv: T={T}, K={K}, stride={stride} leaves no output frame")
+    fl = _flags(math, out_bf16)
+    nbytes = _capi.lib().stgcn_tcn_packed_bytes(Cin, Cout, K, fl)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    y = torch.empty(N, Cout, Tout, V, device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_tcn_forward", _dev_ptr(x, "x", dev), _dev_ptr(W, "W", dev),
+                   _dev_ptr(scale, "scale", dev), _dev_ptr(shift, "shift", dev), c_void_p(y.data_ptr()),
+                   c_int(N), c_int(Cin), c_int(Cout), c_int(T), c_int(V), c_int(K), c_int(stride),
+                   c_void_p(ws.data_ptr()), c_size_t(nbytes), c_uint(fl), _stream(dev))
+    return y
+
+
+def stem_supported(Cin, C, T, V, K, S, math=MATH_F32) -> bool:
+    return bool(_capi.lib().stgcn_stem_supported(Cin, C, T, V, K, S, _flags(math, False)))
+
+
+def stem_prepare(Wd, bd, Wdown, bdown, bn_scale, bn_shift, down_scale, down_shift, Wt, t_scale,
+                 math=MATH_F32) -> torch.Tensor:
+    """Fold + pack everything the fused stem kernel reads besides x/P; returns the prep blob."""
+    dev = Wd.device
+    S, C, Cin = Wd.shape
+    K = Wt.shape[2]
+    fl = _flags(math, False)
+    nbytes = _capi.lib().stgcn_stem_prep_bytes(Cin, C, K, S, fl)
+    prep = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_stem_prepare", _dev_ptr(Wd, "Wd", dev), _dev_ptr(bd, "bd", dev),
+                   _dev_ptr(Wdown, "Wdown", dev), _dev_ptr(bdown, "bdown", dev),
+                   _dev_ptr(bn_scale, "bn_scale", dev), _dev_ptr(bn_shift, "bn_shift", dev),
+                   _dev_ptr(down_scale, "down_scale", dev), _dev_ptr(down_shift, "down_shift", dev),
+                   _dev_ptr(Wt, "Wt", dev), _dev_ptr(t_scale, "t_scale", dev), c_void_p(prep.data_ptr()),
+                   c_int(Cin), c_int(C), c_int(K), c_int(S), c_uint(fl), _stream(dev))
+    return prep
+
+
+def stem_forward(x, A_eff, Wa, ba, Wb, bb, prep, t_shift, C, K, math=MATH_F32, out_bf16=False,
+                 out: Optional[torch.Tensor] = None, P_ws: Optional[torch.Tensor] = None):
+    """Fused tcn0(gcn0(x)).  Returns (out (N,C,T,V), P (N,S,V,V))."""
+    dev = x.device
+    N, Cin, T, V = x.shape
+    S, inter_c, _ = Wa.shape
+    odt = torch.bfloat16 if out_bf16 else torch.float32
+    if out is None:
+        out = torch.empty(N, C, T, V, device=dev, dtype=odt)
+    elif out.shape != (N, C, T, V) or out.dtype != odt or not out.is_contiguous() or out.device != dev:
+        raise ValueError("stem_forward: `out` has the wrong shape/dtype/device")
+    if P_ws is None:
+        P_ws = torch.empty(N, S, V, V, device=dev, dtype=torch.float32)
+    st = _stream(dev)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_agcn_attention", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev),
+                   _dev_ptr(Wa, "Wa", dev), _dev_ptr(ba, "ba", dev), _dev_ptr(Wb, "Wb", dev),
+                   _dev_ptr(bb, "bb", dev), _dev_ptr(P_ws, "P_ws", dev), c_int(N), c_int(Cin), c_int(T),
+                   c_int(V), c_int(inter_c), c_int(S), st)
+        timer = kernel_timer
+        if timer is not None:
+            timer.start("stem_tail", dev)
+        _capi.call("stgcn_stem_tail_prepared", _dev_ptr(x, "x", dev), _dev_ptr(P_ws, "P_ws", dev),
+                   c_void_p(prep.data_ptr()), _dev_ptr(t_shift, "t_shift", dev), c_void_p(out.data_ptr()),
+                   c_int(N), c_int(Cin), c_int(C), c_int(T), c_int(V), c_int(S), c_int(K),
+                   c_uint(_flags(math, out_bf16)), st)
+        if timer is not None:
+            timer.stop("stem_tail", dev)
+    return out, P_ws
+
+
+class KernelTimer:
+    """HIP-event bracket around individual kernel launches on the launching stream.
+
+    Assign an instance to ``functional.kernel_timer`` to have the wrappers record an event pair per
+    launch (no synchronisation while recording); ``mean_ms(name)`` synchronises and averages.
+    """
+
+    def __init__(self):
+        self.pairs = {}
+        self._open = {}
+
+    def start(self, name, dev):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(dev))
+        self._open[name] = ev
+
+    def stop(self, name, dev):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(dev))
+        self.pairs.setdefault(name, []).append((self._open.pop(name), ev))
+
+    def reset(self):
+        self.pairs.clear()
+        self._open.clear()
+
+    def count(self, name):
+        return len(self.pairs.get(name, []))
+
+    def mean_ms(self, name):
+        pairs = self.pairs.get(name, [])
+        if not pairs:
+            return None
+        pairs[-1][1].synchronize()
+        return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+
+
+kernel_timer: Optional[KernelTimer] = None

@@ -1,0 +1,314 @@
+"""nn.Module mirror of the reference's ST-GCN stem, running on libstgcn_hip.so.
+
+``unit_agcn`` <- model/unit_agcn.py:31-93, ``Unit2D`` <- model/net.py:7-57 of the reference: same
+constructor arguments, sub-module / parameter names (so existing ``.pth`` files load strictly),
+initialisation and error behaviour.  ``forward`` hands raw device pointers to the HIP kernels;
+there is no torch-op implementation of the math in this package.
+
+Eval-mode parameters are folded/packed once and cached; the cache is keyed on the version
+counters of every parameter and buffer, so an optimizer step, ``load_state_dict`` or a manual
+in-place edit invalidates it automatically.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from ._capi import MATH_BF16, MATH_BF16X3, MATH_F32, MATH_F32_VALU
+
+_MATH_NAMES = {"f32": MATH_F32, "bf16x3": MATH_BF16X3, "bf16": MATH_BF16, "f32_valu": MATH_F32_VALU}
+
+
+def _default_math() -> int:
+    return _MATH_NAMES[os.environ.get("STGCN_MATH", "f32").lower()]
+
+
+def _identity(x):
+    return x
+
+
+def _versions(mod: nn.Module):
+    return tuple(t._version for t in list(mod.parameters()) + list(mod.buffers()))
+
+
+def _require_inference(mod: nn.Module, x: torch.Tensor):
+    if mod.training:
+        raise NotImplementedError(
+            f"{type(mod).__name__}: training-mode forward (batch-statistics BatchNorm + autograd) is not "
+            "implemented by the HIP path yet; call .eval() (SURVEY.md §8f rank 2)")
+    if not x.is_cuda:
+        raise RuntimeError(
+            f"{type(mod).__name__}: input is on {x.device}; the HIP path runs on the GPU only "
+            "(there is deliberately no CPU fallback)")
+    if x.dtype != torch.float32:
+        raise TypeError(f"{type(mod).__name__}: input must be float32 (got {x.dtype})")
+    if x.dim() != 4:
+        raise ValueError(f"{type(mod).__name__}: expected (N,C,T,V), got {tuple(x.shape)}")
+
+
+# ----------------------------------------------------------------------------------------
+def conv_init(module):
+    """He-normal on the weight only (model/net.py:60-65)."""
+    n = module.out_channels
+    for k in module.kernel_size:
+        n = n * k
+    module.weight.data.normal_(0, math.sqrt(2. / n))
+
+
+def import_class(name):
+    """'graph.SHRE' -> class; prints the name like the reference does (model/net.py:68-74)."""
+    print("name", name)
+    components = name.split('.')
+    mod = __import__(components[0])
+    for comp in components[1:]:
+        mod = getattr(mod, comp)
+    return mod
+
+
+def _agcn_conv_init(conv):          # model/unit_agcn.py:12-14
+    nn.init.kaiming_normal_(conv.weight, mode='fan_out')
+    nn.init.constant_(conv.bias, 0)
+
+
+def _bn_init(bn, scale):            # model/unit_agcn.py:17-19
+    nn.init.constant_(bn.weight, scale)
+    nn.init.constant_(bn.bias, 0)
+
+
+def _conv_branch_init(conv, branches):   # model/unit_agcn.py:22-28
+    n, k1, k2 = conv.weight.size(0), conv.weight.size(1), conv.weight.size(2)
+    nn.init.normal_(conv.weight, 0, math.sqrt(2. / (n * k1 * k2 * branches)))
+    nn.init.constant_(conv.bias, 0)
+
+
+# ----------------------------------------------------------------------------------------
+class unit_agcn(nn.Module):
+    """Adaptive graph convolution; signature and state_dict of model/unit_agcn.py:31-71.
+
+    Note on ``A``: like the reference, ``PA`` is created *on A's storage* and then filled with
+    1e-6 (model/unit_agcn.py:37-39), so the caller's tensor and ``self.A`` both read 1e-6 after
+    construction and the skeleton adjacency is effectively learned from scratch through ``PA``.
+    This is reproduced on purpose (results must match the reference for the same checkpoint);
+    assign ``module.A = graph_tensor`` afterwards to use the true graph as the fixed term.
+    ``use_local_bn`` / ``mask_learning`` are accepted and ignored, as in the reference.
+    """
+
+    def __init__(self, in_channels, out_channels, A, coff_embedding=4, num_subset=3, use_local_bn=False,
+                 mask_learning=False):
+        super().__init__()
+        inter_channels = out_channels // coff_embedding
+        self.inter_c = inter_channels
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.PA = nn.Parameter(A)
+        nn.init.constant_(self.PA, 1e-6)
+        self.A = A                      # plain attribute: not a buffer, not in state_dict, never moved by .cuda()
+        self.num_subset = num_subset
+
+        self.conv_a = nn.ModuleList()
+        self.conv_b = nn.ModuleList()
+        self.conv_d = nn.ModuleList()
+        for _ in range(self.num_subset):
+            self.conv_a.append(nn.Conv2d(in_channels, inter_channels, 1))
+            self.conv_b.append(nn.Conv2d(in_channels, inter_channels, 1))
+            self.conv_d.append(nn.Conv2d(in_channels, out_channels, 1))
+
+        if in_channels != out_channels:
+            self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels))
+        else:
+            self.down = _identity
+
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.soft = nn.Softmax(-2)      # kept for attribute parity; the soft-max runs inside the HIP kernel
+        self.relu = nn.ReLU()
+
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                _agcn_conv_init(m)
+            elif isinstance(m, nn.BatchNorm2d):
+                _bn_init(m, 1)
+        _bn_init(self.bn, 1e-6)
+        for i in range(self.num_subset):
+            _conv_branch_init(self.conv_d[i], self.num_subset)
+
+        self._cache = None
+        self._fused_tcn: Optional["Unit2D"] = None
+        self.last_attention: Optional[torch.Tensor] = None   # P (N,S,V,V) of the latest forward
+
+    # -- parameter staging ---------------------------------------------------------------
+    def _has_down(self) -> bool:
+        return isinstance(self.down, nn.Sequential)
+
+    def _staged(self, device):
+        """Stacked / folded device tensors for the C ABI, cached until any parameter changes."""
+        key = (device, _versions(self), self.A._version, id(self.A))
+        if self._cache is not None and self._cache["key"] == key:
+            return self._cache
+        with torch.no_grad():
+            S = self.num_subset
+            stack_w = lambda convs: torch.stack([c.weight.reshape(c.out_channels, c.in_channels) for c in convs]).to(
+                device=device, dtype=torch.float32).contiguous()
+            stack_b = lambda convs: torch.stack([c.bias for c in convs]).to(device=device, dtype=torch.float32).contiguous()
+            st = {"key": key}
+            # A = self.A.cuda(dev) + self.PA  (model/unit_agcn.py:75-76); uploaded once, not per call
+            st["A_eff"] = (self.A.to(device=device, dtype=torch.float32) + self.PA.to(device)).contiguous()
+            st["Wa"], st["ba"] = stack_w(self.conv_a), stack_b(self.conv_a)
+            st["Wb"], st["bb"] = stack_w(self.conv_b), stack_b(self.conv_b)
+            st["Wd"], st["bd"] = stack_w(self.conv_d), stack_b(self.conv_d)
+            bn = self.bn
+            st["bn_scale"], st["bn_shift"] = F.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                       None, bn.eps)
+            if self._has_down():
+                dc, dbn = self.down[0], self.down[1]
+                st["Wdown"] = dc.weight.reshape(dc.out_channels, dc.in_channels).to(
+                    device=device, dtype=torch.float32).contiguous()
+                st["bdown"] = dc.bias.to(device=device, dtype=torch.float32).contiguous()
+                st["down_scale"], st["down_shift"] = F.bn_fold(dbn.weight, dbn.bias, dbn.running_mean,
+                                                               dbn.running_var, None, dbn.eps)
+            else:
+                st["Wdown"] = st["bdown"] = st["down_scale"] = st["down_shift"] = None
+            assert S == st["Wd"].shape[0]
+        self._cache = st
+        return st
+
+    def _fusable(self, x) -> bool:
+        t = self._fused_tcn
+        if t is None or getattr(self, "_is_replica", False) or t.training or not self._has_down():
+            return False
+        if t.dim != 2 or t.stride != 1 or t.conv.in_channels != self.out_channels \
+                or t.conv.out_channels != self.out_channels:
+            return False
+        if t.conv.weight.device != x.device:
+            return False
+        _, C, T, V = x.shape
+        return F.stem_supported(C, self.out_channels, T, V, t.kernel_size, self.num_subset, t.math_mode)
+
+    def forward(self, x):
+        _require_inference(self, x)
+        if x.shape[1] != self.in_channels:
+            raise RuntimeError(f"unit_agcn: expected {self.in_channels} input channels, got {x.shape[1]}")
+        if x.shape[3] != self.PA.shape[-1]:
+            raise RuntimeError(f"unit_agcn: input has {x.shape[3]} joints, adjacency has {self.PA.shape[-1]}")
+        x = x.contiguous()
+        st = self._staged(x.device)
+        if self._fusable(x):
+            t = self._fused_tcn
+            ts = t._staged(x.device)
+            pkey = (st["key"], ts["key"], t.math_mode)
+            if st.get("stem_key") != pkey:
+                st["stem_prep"] = F.stem_prepare(st["Wd"], st["bd"], st["Wdown"], st["bdown"], st["bn_scale"],
+                                                 st["bn_shift"], st["down_scale"], st["down_shift"], ts["W"],
+                                                 ts["scale"], t.math_mode)
+                st["stem_key"] = pkey
+            out, P = F.stem_forward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["stem_prep"],
+                                    ts["shift"], self.out_channels, t.kernel_size, t.math_mode, t.out_bf16)
+            self.last_attention = P
+            out._stgcn_fused_for = t          # Unit2D.forward recognises its own pre-computed output
+            return out
+        y, P = F.agcn_forward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"],
+                              st["Wdown"], st["bdown"], st["bn_scale"], st["bn_shift"], st["down_scale"],
+                              st["down_shift"])
+        self.last_attention = P
+        return y
+
+
+# ----------------------------------------------------------------------------------------
+class Unit2D(nn.Module):
+    """Dropout -> Conv2d((k,1)) -> BatchNorm2d -> ReLU; signature of model/net.py:7-45.
+
+    ``dim=3`` (conv along the joint axis, never used by the reference's models) runs the same
+    kernel on the (T,V)-transposed tensor.  ``math_mode`` picks the contraction arithmetic
+    (``stgcn_amd.MATH_F32`` default, env ``STGCN_MATH``); shapes the matrix-core kernel does not
+    cover run on the fp32 VALU kernel.
+    """
+
+    def __init__(self, D_in, D_out, kernel_size, stride=1, dim=2, dropout=0, bias=True):
+        super().__init__()
+        pad = int((kernel_size - 1) / 2)
+        if dim == 2:
+            self.conv = nn.Conv2d(D_in, D_out, kernel_size=(kernel_size, 1), padding=(pad, 0),
+                                  stride=(stride, 1), bias=bias)
+        elif dim == 3:
+            self.conv = nn.Conv2d(D_in, D_out, kernel_size=(1, kernel_size), padding=(0, pad),
+                                  stride=(1, stride), bias=bias)
+        else:
+            raise ValueError()
+        self.bn = nn.BatchNorm2d(D_out)
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(dropout, inplace=False)
+        conv_init(self.conv)
+
+        self.dim = dim
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.math_mode = _default_math()
+        self.out_bf16 = False
+        self._cache = None
+
+    def _staged(self, device):
+        key = (device, _versions(self), self.math_mode)
+        if self._cache is not None and self._cache["key"] == key:
+            return self._cache
+        with torch.no_grad():
+            c, bn = self.conv, self.bn
+            W = c.weight.reshape(c.out_channels, c.in_channels, self.kernel_size).to(
+                device=device, dtype=torch.float32).contiguous()
+            scale, shift = F.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, c.bias, bn.eps)
+            st = {"key": key, "W": W, "scale": scale, "shift": shift, "packed": {}}
+        self._cache = st
+        return st
+
+    def _packed(self, st, math_mode):
+        if math_mode not in st["packed"]:
+            st["packed"][math_mode] = F.tcn_pack(st["W"], st["scale"], math_mode)
+        return st["packed"][math_mode]
+
+    def forward(self, x):
+        if getattr(x, "_stgcn_fused_for", None) is self:
+            return x                      # produced by the fused stem kernel in unit_agcn.forward
+        _require_inference(self, x)       # eval: dropout is the identity (model/net.py:48)
+        if x.shape[1] != self.conv.in_channels:
+            raise RuntimeError(f"Unit2D: expected {self.conv.in_channels} input channels, got {x.shape[1]}")
+        if self.dim == 3:
+            x = x.transpose(2, 3)
+        x = x.contiguous()
+        N, Cin, T, V = x.shape
+        st = self._staged(x.device)
+        mode = self.math_mode
+        if mode != MATH_F32_VALU and not F.tcn_supported(Cin, self.conv.out_channels, T, V, self.kernel_size,
+                                                         self.stride, mode):
+            mode = MATH_F32_VALU
+        y = F.tcn_forward_packed(x, self._packed(st, mode), st["shift"], self.conv.out_channels,
+                                 self.kernel_size, self.stride, mode, self.out_bf16)
+        if self.dim == 3:
+            y = y.transpose(2, 3).contiguous()
+        return y
+
+
+# ----------------------------------------------------------------------------------------
+def enable_stem_fusion(gcn: unit_agcn, tcn: Unit2D) -> None:
+    """Make ``tcn(gcn(x))`` run as ONE fused kernel pair (attention + fused stem).
+
+    Both modules stay where they are (state_dict keys and the caller's forward are untouched):
+    ``gcn.forward`` computes the whole stem and tags the result, ``tcn.forward`` passes a tensor
+    carrying its own tag straight through.  Falls back to the two-stage path whenever the fused
+    kernel does not cover the shape, under nn.DataParallel replicas, or in training mode.
+    """
+    object.__setattr__(gcn, "_fused_tcn", tcn)
+
+
+def disable_stem_fusion(gcn: unit_agcn) -> None:
+    object.__setattr__(gcn, "_fused_tcn", None)
+
+
+def set_math_mode(module: nn.Module, mode) -> None:
+    """Set the temporal-conv arithmetic ('f32' | 'bf16x3' | 'bf16' | 'f32_valu') on every Unit2D below."""
+    m = _MATH_NAMES[mode] if isinstance(mode, str) else int(mode)
+    for sub in module.modules():
+        if isinstance(sub, Unit2D):
+            sub.math_mode = m

@@ -1,0 +1,263 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): HIP path vs golden fixtures and the CPU oracle.
+
+Gate (north_star): fp32 within 1e-4 relative — ``max|out-ref| <= 1e-4*max|ref|`` and
+``allclose(rtol=1e-4, atol=1e-5*max|ref|)``.  Every call goes through the C ABI
+(stgcn_amd.functional -> ctypes -> libstgcn_hip.so); the oracle is only the checker.
+"""
+import numpy as np
+import pytest
+import torch
+
+from _util import gather_flat, load_golden, parity_gate, sub_state
+
+pytestmark = pytest.mark.gpu
+
+GCN_CASES = {  # name -> (cin, cout)
+    "gcn_shre_3_128_quirk": (3, 128), "gcn_shre_3_128_trueA": (3, 128),
+    "gcn_shre_3_128_default_init": (3, 128), "gcn_lmdhg_3_128": (3, 128),
+    "gcn_shre_64_64_identity": (64, 64), "gcn_shre_64_128": (64, 128),
+}
+TCN_CASES = {  # name -> (cin, cout, K, stride, bias)
+    "tcn_128_128_k9": (128, 128, 9, 1, True), "tcn_64_128_k9_s2": (64, 128, 9, 2, True),
+    "tcn_64_128_k1_s2": (64, 128, 1, 2, True), "tcn_128_128_k9_v46": (128, 128, 9, 1, True),
+    "tcn_32_64_k5_nobias": (32, 64, 5, 1, False),
+}
+STEM_CASES = ["stem_shre_T180", "stem_lmdhg_T200", "stem_shre_T500"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import stgcn_amd
+    stgcn_amd.lib()          # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def build_gcn(g, cin, cout, dev):
+    from stgcn_amd import unit_agcn
+    m = unit_agcn(cin, cout, torch.from_numpy(g["A_true"]).clone() if "A_true" in g
+                  else torch.zeros_like(torch.from_numpy(g["A_fixed"])))
+    m.load_state_dict(sub_state(g, "gcn."), strict=True)
+    m = m.to(dev).eval()
+    m.A = torch.from_numpy(g["A_fixed"]).clone()       # plain CPU attribute, like the reference's self.A
+    return m
+
+
+def build_tcn(g, cin, cout, K, stride, bias, dev, math="f32"):
+    from stgcn_amd import Unit2D, set_math_mode
+    m = Unit2D(cin, cout, kernel_size=K, stride=stride, bias=bias)
+    m.load_state_dict(sub_state(g, "tcn."), strict=True)
+    m = m.to(dev).eval()
+    set_math_mode(m, math)
+    return m
+
+
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", sorted(GCN_CASES))
+def test_agcn_vs_golden(case, dev):
+    g = load_golden(case)
+    cin, cout = GCN_CASES[case]
+    m = build_gcn(g, cin, cout, dev)
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x"]).to(dev))
+    parity_gate(m.last_attention, g["P_eval"], 1e-4, f"{case} P")
+    parity_gate(y, g["y_eval"], 1e-4, f"{case} y")
+
+
+def test_agcn_T180_samples(dev):
+    g = load_golden("gcn_shre_3_128_T180")
+    m = build_gcn(g, 3, 128, dev)
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x"]).to(dev)).cpu()
+    parity_gate(m.last_attention, g["P_eval"], 1e-4, "P")
+    scale = float(g["y_eval_absmax"])
+    err = (gather_flat(y, g["y_eval_idx"]).double() - torch.from_numpy(g["y_eval_val"]).double()).abs().max().item()
+    assert err <= 1e-4 * scale
+    assert float(y.double().sum()) == pytest.approx(float(g["y_eval_sum"]), rel=1e-4)
+
+
+@pytest.mark.parametrize("math", ["f32", "f32_valu"])
+@pytest.mark.parametrize("case", sorted(TCN_CASES))
+def test_tcn_vs_golden(case, math, dev):
+    g = load_golden(case)
+    cin, cout, K, stride, bias = TCN_CASES[case]
+    m = build_tcn(g, cin, cout, K, stride, bias, dev, math)
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x"]).to(dev))
+    parity_gate(y, g["y_eval"], 1e-4, f"{case} {math}")
+
+
+def test_tcn_one_shot_entry_point(dev):
+    """stgcn_tcn_forward (pack + run in one call) agrees with the packed path."""
+    from stgcn_amd import functional as F
+    g = load_golden("tcn_128_128_k9")
+    m = build_tcn(g, 128, 128, 9, 1, True, dev)
+    st = m._staged(dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    y = F.tcn_forward(x, st["W"], st["scale"], st["shift"], 1, F.MATH_F32)
+    parity_gate(y, g["y_eval"], 1e-4, "one-shot")
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_stem_vs_golden(case, fused, dev):
+    from stgcn_amd import enable_stem_fusion
+    g = load_golden(case)
+    gcn = build_gcn(g, 3, 128, dev)
+    tcn = build_tcn(g, 128, 128, 9, 1, True, dev)
+    if fused:
+        enable_stem_fusion(gcn, tcn)
+    x = torch.from_numpy(g["skeleton"]).to(dev).permute(0, 3, 1, 2).contiguous()   # ST_GCN_AltFormer.py:64-68
+    with torch.no_grad():
+        y = gcn(x)
+        z = tcn(y)
+    if fused:
+        assert z is y, "fused stem must hand tcn0 its own output"
+    parity_gate(gcn.last_attention, g["P_eval"], 1e-4, "P")
+    checks = [("z", z)] if fused else [("y", y), ("z", z)]
+    for nm, arr in checks:
+        arr = arr.cpu()
+        scale = float(g[f"{nm}_eval_absmax"])
+        err = (gather_flat(arr, g[f"{nm}_eval_idx"]).double()
+               - torch.from_numpy(g[f"{nm}_eval_val"]).double()).abs().max().item()
+        assert err <= 1e-4 * scale, f"{case} {nm}: {err:.3e} vs {scale:.3e}"
+        assert float(arr.double().sum()) == pytest.approx(float(g[f"{nm}_eval_sum"]), rel=1e-4, abs=1e-3 * scale)
+        assert float((arr.double() ** 2).sum()) == pytest.approx(float(g[f"{nm}_eval_sumsq"]), rel=2e-4)
+
+
+# ---------------------------------------------------------------------------------------
+# seeded comparisons against the oracle at shapes the fixtures do not hold (ragged tiles, odd V)
+# ---------------------------------------------------------------------------------------
+def _random_stem(V, graph, seed, dev, cin=3, c=128):
+    from stgcn_amd import Unit2D, unit_agcn
+    from oracle import stgcn_oracle as so
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed)
+    A = torch.rand(3, V, V, generator=gen) * (torch.rand(3, V, V, generator=gen) < 0.15) if graph is None else graph
+    gcn = unit_agcn(cin, c, A.clone())
+    tcn = Unit2D(c, c, kernel_size=9)
+    with torch.no_grad():
+        gcn.PA.data = torch.randn(3, V, V, generator=gen) * 0.05
+        for m in list(gcn.modules()) + list(tcn.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.num_features, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.num_features, generator=gen) * 0.2)
+                m.running_mean.copy_(torch.randn(m.num_features, generator=gen) * 0.3)
+                m.running_var.copy_(torch.rand(m.num_features, generator=gen) * 1.5 + 0.25)
+            if isinstance(m, torch.nn.Conv2d):
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+        for cv in list(gcn.conv_a) + list(gcn.conv_b):
+            cv.weight.mul_(3.0)
+    gcn.A = A.clone()
+    gp = so.agcn_params_from_state(gcn.state_dict(), gcn.A)
+    tp = so.tcn_params_from_state(tcn.state_dict())
+    return gcn.to(dev).eval(), tcn.to(dev).eval(), gp, tp, gen
+
+
+@pytest.mark.parametrize("N,T,V", [(3, 37, 22), (2, 9, 46), (1, 5, 22), (2, 64, 25), (1, 1, 22), (2, 23, 7)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_stem_vs_oracle_ragged(N, T, V, fused, dev):
+    from stgcn_amd import enable_stem_fusion
+    from oracle import stgcn_oracle as so
+    gcn, tcn, gp, tp, gen = _random_stem(V, None, 100 + T + V, dev)
+    if fused:
+        enable_stem_fusion(gcn, tcn)
+    x = torch.randn(N, 3, T, V, generator=gen)
+    aux = {}
+    ref = so.stem_forward(x.double(), gp.to(torch.float64), tp.to(torch.float64), aux=aux)
+    with torch.no_grad():
+        y = gcn(x.to(dev))
+        z = tcn(y)
+    parity_gate(gcn.last_attention, aux["gcn"]["P"], 1e-4, "P")
+    if not fused:
+        parity_gate(y, aux["gcn_out"], 1e-4, "gcn out")
+    parity_gate(z, ref, 1e-4, "stem out")
+
+
+@pytest.mark.parametrize("cin,cout,K,stride,T,V", [
+    (128, 128, 9, 1, 41, 22), (64, 128, 9, 2, 40, 22), (128, 256, 9, 2, 33, 22), (256, 256, 9, 1, 12, 46),
+    (16, 128, 3, 1, 7, 22), (48, 96, 9, 1, 20, 22), (128, 128, 1, 1, 30, 22), (64, 64, 9, 1, 25, 22)])
+def test_tcn_vs_oracle_shapes(cin, cout, K, stride, T, V, dev):
+    from stgcn_amd import Unit2D
+    from oracle import stgcn_oracle as so
+    gen = torch.Generator().manual_seed(cin + cout + K + T)
+    torch.manual_seed(5)
+    m = Unit2D(cin, cout, kernel_size=K, stride=stride)
+    with torch.no_grad():
+        m.conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
+        m.bn.weight.copy_(torch.rand(cout, generator=gen) + 0.5)
+        m.bn.bias.copy_(torch.randn(cout, generator=gen) * 0.2)
+        m.bn.running_mean.copy_(torch.randn(cout, generator=gen) * 0.3)
+        m.bn.running_var.copy_(torch.rand(cout, generator=gen) + 0.25)
+    tp = so.tcn_params_from_state(m.state_dict(), stride=stride).to(torch.float64)
+    x = torch.randn(2, cin, T, V, generator=gen)
+    ref = so.tcn_forward(x.double(), tp)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        y = m(x.to(dev))
+    parity_gate(y, ref, 1e-4, f"tcn {cin}->{cout} K{K} s{stride}")
+
+
+def test_unit2d_dim3(dev):
+    """dim=3 (conv along joints) = the same op on the (T,V)-transposed tensor."""
+    from stgcn_amd import Unit2D
+    from oracle import stgcn_oracle as so
+    torch.manual_seed(9)
+    m = Unit2D(32, 128, kernel_size=3, dim=3)
+    x = torch.randn(2, 32, 10, 22)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["conv.weight"] = sd["conv.weight"].permute(0, 1, 3, 2)        # (Cout,Cin,1,K) -> (Cout,Cin,K,1)
+    tp = so.tcn_params_from_state(sd).to(torch.float64)
+    ref = so.tcn_forward(x.double().transpose(2, 3), tp).transpose(2, 3)
+    with torch.no_grad():
+        y = m.to(dev).eval()(x.to(dev))
+    parity_gate(y, ref, 1e-4, "dim=3")
+
+
+# ---------------------------------------------------------------------------------------
+# full-size properties (BASELINE config 2 shape: N=256, T=180, V=22)
+# ---------------------------------------------------------------------------------------
+def test_full_size_properties(dev):
+    from stgcn_amd import enable_stem_fusion, disable_stem_fusion
+    from stgcn_amd.graphs import SHREGraph
+    from oracle import stgcn_oracle as so
+    A = torch.from_numpy(SHREGraph("spatial").A.astype(np.float32))
+    gcn, tcn, gp, tp, gen = _random_stem(22, A, 77, dev)
+    N, T, V = 256, 180, 22
+    x = torch.randn(N, T, V, 3, generator=gen).permute(0, 3, 1, 2).contiguous()
+    xd = x.to(dev)
+    with torch.no_grad():
+        z_two = tcn(gcn(xd))
+        enable_stem_fusion(gcn, tcn)
+        z_fused = tcn(gcn(xd))
+        # clip independence: a clip computed alone equals the same clip inside the batch, bit for bit
+        sel = [0, 97, 255]
+        z_sel = tcn(gcn(xd[sel].contiguous()))
+        assert torch.equal(z_sel, z_fused[sel])
+        # batch permutation equivariance
+        perm = torch.randperm(N, generator=gen)
+        z_perm = tcn(gcn(xd[perm.to(dev)].contiguous()))
+        assert torch.equal(z_perm, z_fused[perm.to(dev)])
+        disable_stem_fusion(gcn)
+    assert torch.isfinite(z_fused).all()
+    assert (z_fused >= 0).all()
+    parity_gate(z_fused, z_two, 1e-5, "fused vs two-stage")
+    # three clips of the big batch against the fp64 oracle
+    ref = so.stem_forward(x[sel].double(), gp.to(torch.float64), tp.to(torch.float64))
+    parity_gate(z_fused[sel], ref, 1e-4, "full-size clips vs oracle")
+
+
+def test_errors_are_loud(dev):
+    from stgcn_amd import Unit2D, functional as F, StgcnError
+    m = Unit2D(8, 8, kernel_size=3).to(dev)
+    with pytest.raises(NotImplementedError):
+        m.train()(torch.zeros(1, 8, 4, 4, device=dev))
+    with pytest.raises(RuntimeError):
+        m.eval()(torch.zeros(1, 8, 4, 4))            # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        Unit2D(8, 8, kernel_size=3, dim=4)
+    x = torch.zeros(1, 8, 4, 4, device=dev)
+    with pytest.raises(StgcnError):
+        F.tcn_forward_packed(x, torch.zeros(16, device=dev, dtype=torch.uint8), torch.zeros(8, device=dev), 8, 3,
+                             math=F.MATH_BF16)       # not built -> STGCN_ERR_UNSUPPORTED, not a silent fallback

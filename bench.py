@@ -70,7 +70,11 @@ def cpu_baseline(gcn, tcn, T, V, clips, reps):
     gp = so.agcn_params_from_state({k: v.cpu() for k, v in gcn.state_dict().items()}, gcn.A.cpu())
     tp = so.tcn_params_from_state({k: v.cpu() for k, v in tcn.state_dict().items()})
     x = synthetic_clips(clips, T, V, 0)
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("STGCN_CPU_THREADS", "16"))))   # the GPU box's CPU share is 16
     torch.set_num_threads(cores)
     times = []
     with torch.no_grad():

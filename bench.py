@@ -176,7 +176,8 @@ def main():
         if kern_ms:
             achieved = flops_clip * n_local / (kern_ms * 1e-3)
             peak = MFMA_PEAK[args.math]
-            roof = {"bound": "mfma", "kernel": "stem_mfma_f32_kernel" if args.math == "f32" else "stem_" + args.math,
+            roof = {"bound": "mfma",
+                    "kernel": "stem_mfma_f32_kernel" if args.math == "f32" else "tcn_mfma_bf16_kernel<fused>",
                     "achieved": round(achieved / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
                     "kernel_ms": round(kern_ms, 4), "launches_timed": timer.count("stem_tail"),

@@ -63,6 +63,14 @@ int launch_tcn_pack(const float *W, const float *scale, void *Wp, int Cin, int C
 int launch_tcn(const float *x, const void *Wp, const float *shift, void *y, int N, int Cin,
                int Cout, int T, int V, int K, int stride, unsigned flags, hipStream_t st);
 
+// bf16 matrix-core variants (tcn_bf16.hip)
+bool bf16_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags, bool fused);
+bool bf16_packs(int Cin, int Cout, unsigned math);
+int launch_tcn_pack_bf16(const float *W, const float *scale, void *Wp, int Cin, int Cout, int K, hipStream_t st);
+int launch_tcn_bf16(const float *x, const float *P, const float *W12, const void *Wp, const float *shift, void *y,
+                    int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags, bool fused,
+                    hipStream_t st);
+
 bool tcn_mfma_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
 bool stem_fused_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags);
 

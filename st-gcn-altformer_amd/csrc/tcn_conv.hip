@@ -147,27 +147,44 @@ __device__ __forceinline__ void lane_b_offsets(const TileGeom &g, int lane, int 
     }
 }
 
-// 4 MFMAs of one k-step (channel pair c2 of the chunk) against the 4 pixel blocks
-__device__ __forceinline__ void mfma_kstep(f32x16 (&acc)[4], float a, const float *__restrict__ b,
-                                           int o0, int o1, int o2, int o3) {
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[o0], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[o1], acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[o2], acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[o3], acc[3], 0, 0, 0);
+// B operands of one k-step: one float per lane for each of the 4 pixel blocks
+struct B4 {
+    float v0, v1, v2, v3;
+};
+
+__device__ __forceinline__ B4 load_b4(const float *__restrict__ b, int o0, int o1, int o2, int o3) {
+    return B4{b[o0], b[o1], b[o2], b[o3]};
 }
 
-// 32 MFMAs of one tap of one chunk: 8 k-steps (channel pairs) x 4 pixel blocks
+// One k-step, software-pipelined: issue the LDS reads of the NEXT k-step, then the 4 MFMAs of this one
+// (channel pair c2 of the chunk against the 4 pixel blocks).  hipcc otherwise groups 8 ds_reads in front
+// of 8 MFMAs and the matrix pipe idles for one LDS latency per group.
+#define STGCN_KSTEP(A, NEXT_PTR)                                                     \
+    do {                                                                             \
+        const B4 bn = load_b4((NEXT_PTR), o0, o1, o2, o3);                           \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A), bq.v0, acc[0], 0, 0, 0);  \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A), bq.v1, acc[1], 0, 0, 0);  \
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32((A), bq.v2, acc[2], 0, 0, 0);  \
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32((A), bq.v3, acc[3], 0, 0, 0);  \
+        bq = bn;                                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                           \
+    } while (0)
+
+// 32 MFMAs of one tap of one chunk: 8 k-steps x 4 pixel blocks.  On entry bq holds the B operands of
+// k-step 0 of this tap; on exit those of k-step 0 at `nextbuf` (the next tap, or any valid address when
+// there is none).
 __device__ __forceinline__ void mfma_tap(f32x16 (&acc)[4], float4 a0, float4 a1,
-                                         const float *__restrict__ buf, int o0, int o1, int o2, int o3,
-                                         int ROW) {
-    mfma_kstep(acc, a0.x, buf + 0 * ROW, o0, o1, o2, o3);
-    mfma_kstep(acc, a0.y, buf + 2 * ROW, o0, o1, o2, o3);
-    mfma_kstep(acc, a0.z, buf + 4 * ROW, o0, o1, o2, o3);
-    mfma_kstep(acc, a0.w, buf + 6 * ROW, o0, o1, o2, o3);
-    mfma_kstep(acc, a1.x, buf + 8 * ROW, o0, o1, o2, o3);
-    mfma_kstep(acc, a1.y, buf + 10 * ROW, o0, o1, o2, o3);
-    mfma_kstep(acc, a1.z, buf + 12 * ROW, o0, o1, o2, o3);
-    mfma_kstep(acc, a1.w, buf + 14 * ROW, o0, o1, o2, o3);
+                                         const float *__restrict__ buf, const float *__restrict__ nextbuf,
+                                         int o0, int o1, int o2, int o3, int ROW, B4 &bq) {
+    STGCN_KSTEP(a0.x, buf + 2 * ROW);
+    STGCN_KSTEP(a0.y, buf + 4 * ROW);
+    STGCN_KSTEP(a0.z, buf + 6 * ROW);
+    STGCN_KSTEP(a0.w, buf + 8 * ROW);
+    STGCN_KSTEP(a1.x, buf + 10 * ROW);
+    STGCN_KSTEP(a1.y, buf + 12 * ROW);
+    STGCN_KSTEP(a1.z, buf + 14 * ROW);
+    STGCN_KSTEP(a1.w, nextbuf);
 }
 
 template <bool BF16OUT>
@@ -256,6 +273,7 @@ __global__ __launch_bounds__(256) void tcn_mfma_f32_kernel(const float *__restri
         const float *cur = (ch & 1) ? buf1 : buf0;
         float *nxt = (ch & 1) ? buf0 : buf1;
         const bool more = ch + 1 < nch;
+        B4 bq = load_b4(cur, off[0], off[1], off[2], off[3]);
         if (more) prefetch(ch + 1);
         for (int k = 0; k < K; ++k, ++kidx) {
             float4 n0 = a0, n1 = a1;
@@ -263,7 +281,8 @@ __global__ __launch_bounds__(256) void tcn_mfma_f32_kernel(const float *__restri
                 n0 = wp[(size_t)(kidx + 1) * 128];
                 n1 = wp[(size_t)(kidx + 1) * 128 + 64];
             }
-            mfma_tap(acc, a0, a1, cur + k * V, off[0], off[1], off[2], off[3], ROW);
+            mfma_tap(acc, a0, a1, cur + k * V, cur + (k + 1 < K ? k + 1 : k) * V, off[0], off[1], off[2], off[3],
+                     ROW, bq);
             a0 = n0;
             a1 = n1;
         }
@@ -378,13 +397,15 @@ __global__ __launch_bounds__(256) void stem_mfma_f32_kernel(
         const float *cur = (ch & 1) ? buf1 : buf0;
         float *nxt = (ch & 1) ? buf0 : buf1;
         const bool more = ch + 1 < nch;
+        B4 bq = load_b4(cur, off[0], off[1], off[2], off[3]);
         for (int k = 0; k < K; ++k, ++kidx) {
             float4 n0 = a0, n1 = a1;
             if (kidx + 1 < nk) {
                 n0 = wp[(size_t)(kidx + 1) * 128];
                 n1 = wp[(size_t)(kidx + 1) * 128 + 64];
             }
-            mfma_tap(acc, a0, a1, cur + k * V, off[0], off[1], off[2], off[3], ROW);
+            mfma_tap(acc, a0, a1, cur + k * V, cur + (k + 1 < K ? k + 1 : k) * V, off[0], off[1], off[2], off[3],
+                     ROW, bq);
             if (more) {
                 const int c_end = min(CC, (k + 1) * rpt);
                 for (int c = k * rpt; c < c_end; ++c) produce_row(nxt, c, (ch + 1) * CC + c);
@@ -454,10 +475,11 @@ int launch_tcn_pack(const float *W, const float *scale, void *Wp, int Cin, int C
     const unsigned math = flags & STGCN_MATH_MASK;
     const size_t total = (size_t)Cin * Cout * K;
     const int blocks = (int)((total + 255) / 256);
+    if (bf16_packs(Cin, Cout, math)) return launch_tcn_pack_bf16(W, scale, Wp, Cin, Cout, K, st);
     if (packs_as_mfma(Cin, Cout, math)) {
         hipLaunchKernelGGL(tcn_pack_f32_kernel, dim3(blocks), dim3(256), 0, st, W, scale, (float *)Wp, Cin,
                            Cout, K);
-    } else if (math == STGCN_MATH_F32 || math == STGCN_MATH_F32_VALU) {
+    } else if (math <= STGCN_MATH_F32_VALU) {  // shapes the matrix-core kernels do not cover: VALU layout
         hipLaunchKernelGGL(tcn_pack_valu_kernel, dim3(blocks), dim3(256), 0, st, W, scale, (float *)Wp, Cin,
                            Cout, K);
     } else {
@@ -475,8 +497,9 @@ int launch_tcn(const float *x, const void *Wp, const float *shift, void *y, int 
     const int Tout = (T + 2 * pad - K) / stride + 1;
     if (Tout < 1) return fail(STGCN_ERR_ARG, "tcn: T=%d K=%d stride=%d gives no output frame", T, K, stride);
     if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "tcn: N=%d > 65535 clips per call", N);
-    if (math != STGCN_MATH_F32 && math != STGCN_MATH_F32_VALU)
-        return fail(STGCN_ERR_UNSUPPORTED, "tcn: math mode %u not built", math);
+    if (math > STGCN_MATH_F32_VALU) return fail(STGCN_ERR_ARG, "tcn: unknown math mode %u", math);
+    if (bf16_packs(Cin, Cout, math))
+        return launch_tcn_bf16(x, nullptr, nullptr, Wp, shift, y, N, Cin, Cout, T, V, K, stride, flags, false, st);
 
     if (packs_as_mfma(Cin, Cout, math)) {
         if (!mfma_f32_shape_ok(Cin, Cout, V, K, stride, Tout))
@@ -514,6 +537,8 @@ int launch_tcn(const float *x, const void *Wp, const float *shift, void *y, int 
 
 bool tcn_mfma_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags) {
     const unsigned math = flags & STGCN_MATH_MASK;
+    if (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16)
+        return bf16_supported(Cin, Cout, T, V, K, stride, flags, false);
     const int Tout = (T + 2 * ((K - 1) / 2) - K) / stride + 1;
     return Tout >= 1 && packs_as_mfma(Cin, Cout, math) && mfma_f32_shape_ok(Cin, Cout, V, K, stride, Tout);
 }
@@ -536,7 +561,10 @@ static bool stem_shape_ok(int Cin, int C, int V, int K, int S, int T) {
 }
 
 bool stem_fused_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags) {
-    return (flags & STGCN_MATH_MASK) == STGCN_MATH_F32 && T >= 1 && stem_shape_ok(Cin, C, V, K, S, T);
+    const unsigned math = flags & STGCN_MATH_MASK;
+    if (Cin != 3 || S != 3 || T < 1) return false;
+    if (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) return bf16_supported(C, C, T, V, K, 1, flags, true);
+    return math == STGCN_MATH_F32 && stem_shape_ok(Cin, C, V, K, S, T);
 }
 
 int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, const float *bdown,
@@ -544,9 +572,9 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
                         const float *down_shift, const float *Wt, const float *t_scale, void *prep, int Cin,
                         int C, int K, int S, unsigned flags, hipStream_t st) {
     const unsigned math = flags & STGCN_MATH_MASK;
-    if (math != STGCN_MATH_F32)
-        return fail(STGCN_ERR_UNSUPPORTED, "stem: math mode %u not built (fused stem is STGCN_MATH_F32)", math);
-    if ((S + 1) * Cin > 12 || C % 128 != 0)
+    if (math != STGCN_MATH_F32 && math != STGCN_MATH_BF16X3 && math != STGCN_MATH_BF16)
+        return fail(STGCN_ERR_UNSUPPORTED, "stem: no fused kernel for math mode %u", math);
+    if (Cin != 3 || S != 3 || C % 128 != 0)
         return fail(STGCN_ERR_UNSUPPORTED, "stem: fused kernel covers Cin=3, 3 subsets, C%%128==0 (got Cin=%d S=%d C=%d)",
                     Cin, S, C);
     hipLaunchKernelGGL(stem_fold_kernel, dim3(ceil_div(C * W12P, 256)), dim3(256), 0, st, Wd, bd, Wdown, bdown,
@@ -559,9 +587,15 @@ int launch_stem(const float *x, const float *P, const void *prep, const float *t
                 int Cin, int C, int T, int V, int S, int K, unsigned flags, hipStream_t st) {
     const unsigned math = flags & STGCN_MATH_MASK;
     const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
-    if (math != STGCN_MATH_F32)
-        return fail(STGCN_ERR_UNSUPPORTED, "stem: math mode %u not built", math);
     if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "stem: N=%d > 65535 clips per call", N);
+    if (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) {
+        if (Cin != 3 || S != 3)
+            return fail(STGCN_ERR_UNSUPPORTED, "stem: fused kernel covers Cin=3, 3 subsets (got %d, %d)", Cin, S);
+        return launch_tcn_bf16(x, P, (const float *)prep, (const char *)prep + stem_w12_bytes(C), t_shift, out, N, C,
+                               C, T, V, K, 1, flags, true, st);
+    }
+    if (math != STGCN_MATH_F32)
+        return fail(STGCN_ERR_UNSUPPORTED, "stem: no fused kernel for math mode %u", math);
     if (!stem_shape_ok(Cin, C, V, K, S, T))
         return fail(STGCN_ERR_UNSUPPORTED,
                     "stem: fused kernel does not cover Cin=%d S=%d C=%d V=%d K=%d T=%d; call the two-stage path",

@@ -17,7 +17,13 @@ def sub_state(g, prefix):
     return {k[len(prefix):]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith(prefix)}
 
 
-def parity_gate(out, ref, rel=1e-4, what=""):
+# arithmetic modes of the temporal-conv contraction and their gates:
+#   f32 / f32_valu / bf16x3 : the fp32 contract of north_star — 1e-4 relative (both criteria below)
+#   bf16                    : operands rounded to bf16; documented looser bound 1e-2*max|ref| (max-norm only)
+MATH_GATES = {"f32": (1e-4, True), "f32_valu": (1e-4, True), "bf16x3": (1e-4, True), "bf16": (1e-2, False)}
+
+
+def parity_gate(out, ref, rel=1e-4, what="", strict=True):
     """SURVEY §8(d) gate for fp32: max|out-ref| <= rel*max|ref| and allclose(rtol=rel, atol=rel/10*max|ref|)."""
     out = torch.as_tensor(out).double().cpu()
     ref = torch.as_tensor(ref).double().cpu()
@@ -26,7 +32,8 @@ def parity_gate(out, ref, rel=1e-4, what=""):
     scale = ref.abs().max().item()
     err = (out - ref).abs().max().item()
     assert err <= rel * max(scale, 1e-30), f"{what}: max abs err {err:.3e} > {rel:g} * max|ref| ({scale:.3e})"
-    assert torch.allclose(out, ref, rtol=rel, atol=rel * 0.1 * scale), f"{what}: allclose(rtol={rel}) failed"
+    if strict:
+        assert torch.allclose(out, ref, rtol=rel, atol=rel * 0.1 * scale), f"{what}: allclose(rtol={rel}) failed"
     return err / max(scale, 1e-30)
 
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/stgcn_hip.h"
 
@@ -30,6 +31,16 @@ int fail(stgcn_status st, const char *fmt, ...);
             return stgcn::fail(STGCN_ERR_HIP, "launch of %s failed: %s", name,             \
                                hipGetErrorString(_e));                                     \
     } while (0)
+
+// phases switched off by a diagnostic build (see tcn_conv.hip); always 0 in the shipped library
+static inline int ablate_mask() {
+#ifdef STGCN_ABLATION
+    const char *e = getenv("STGCN_ABLATE");
+    return e ? atoi(e) : 0;
+#else
+    return 0;
+#endif
+}
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -32,6 +32,12 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 
+#ifdef STGCN_ABLATION  // diagnostic builds only: 1 = producer, 2 = MFMAs, 4 = epilogue, 8 = B reads, 16 = A loads
+#define STGCN_ABL(bit) ((abl & (bit)) != 0)
+#else
+#define STGCN_ABL(bit) false
+#endif
+
 constexpr int CCB = 32;   // input channels per LDS chunk (two 16-deep k-steps per tap)
 constexpr int PXB = 64;   // bytes per pixel row of one image
 constexpr int W12P = 16;  // row of the folded graph-conv matrix: 12 weights, bias, pad
@@ -147,7 +153,7 @@ template <int NPB, int JPR, int TERMS, bool BF16OUT, bool FUSED>
 __global__ __launch_bounds__(2 * NPB) void tcn_mfma_bf16_kernel(
     const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ W12,
     const uint4 *__restrict__ Wp, const float *__restrict__ shift, void *y, int Cin, int Cout, int T, int V,
-    int K, int stride, int Tout, int ROWS /* pixel rows per image */) {
+    int K, int stride, int Tout, int ROWS /* pixel rows per image */, int abl) {
     constexpr int NT = 2 * NPB;
     constexpr int CIN0 = 3, S = 3, F = 12;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
@@ -297,26 +303,26 @@ __global__ __launch_bounds__(2 * NPB) void tcn_mfma_bf16_kernel(
             uint4 an[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) an[i] = aq[i];
-            if (kidx + 1 < nk) {
+            if (kidx + 1 < nk && !STGCN_ABL(16)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (TERMS == 3 || !(i & 1)) an[i] = wp[((size_t)(kidx + 1) * 4 + i) * 64];
             }
             // k-step 0 of this tap: fetch k-step 1 (same pixels, channel groups q^2 -> address ^ 32)
-            BFrag<TERMS> bn;
-            load_bfrag<TERMS>(bn, cur, img_bytes, addr, 32);
-            mfma_kstep_bf16<TERMS>(acc, aq[0], aq[1], bq);
+            BFrag<TERMS> bn = bq;
+            if (!STGCN_ABL(8)) load_bfrag<TERMS>(bn, cur, img_bytes, addr, 32);
+            if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, aq[0], aq[1], bq);
             __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 8 : 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TERMS == 3 ? 12 : 4, 0);
             // k-step 1: fetch k-step 0 of the next tap (V pixel rows further; same tap again at the end)
             const int kn = (k + 1 < K) ? k + 1 : k;
 #pragma unroll
             for (int j = 0; j < 4; ++j) addr[j] = lds_off(prow[j] + kn * V, h);
-            load_bfrag<TERMS>(bq, cur, img_bytes, addr, 0);
-            mfma_kstep_bf16<TERMS>(acc, aq[2], aq[3], bn);
+            if (!STGCN_ABL(8)) load_bfrag<TERMS>(bq, cur, img_bytes, addr, 0);
+            if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, aq[2], aq[3], bn);
             __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 8 : 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TERMS == 3 ? 12 : 4, 0);
-            if (more) {
+            if (more && !STGCN_ABL(1)) {
                 if (K >= 8) {  // unit u of the next chunk: loads issued at tap 2u, split + LDS store at tap 2u+1
                     if ((k >> 1) < 4) {
                         if (k & 1) produce_unit(nxt, ch + 1, k >> 1);
@@ -338,6 +344,7 @@ __global__ __launch_bounds__(2 * NPB) void tcn_mfma_bf16_kernel(
 
     // epilogue: D[row = channel][col = pixel], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int ppc = Tout * V;
+    if (STGCN_ABL(4)) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int o = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -394,12 +401,12 @@ int launch_variant(const float *x, const float *P, const float *W12, const uint4
         auto kern = tcn_mfma_bf16_kernel<NPB, JPR, TERMS, true, FUSED>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(2 * NPB), pl.lds, st, x, P, W12, Wp, shift, y, Cin, Cout, T, V, K, stride,
-                           Tout, pl.rows);
+                           Tout, pl.rows, ablate_mask());
     } else {
         auto kern = tcn_mfma_bf16_kernel<NPB, JPR, TERMS, false, FUSED>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(2 * NPB), pl.lds, st, x, P, W12, Wp, shift, y, Cin, Cout, T, V, K, stride,
-                           Tout, pl.rows);
+                           Tout, pl.rows, ablate_mask());
     }
     STGCN_LAUNCH_CHECK("tcn_mfma_bf16_kernel");
     return STGCN_OK;

@@ -25,6 +25,14 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// Diagnostic builds (-DSTGCN_ABLATION, never shipped) can switch phases off through env STGCN_ABLATE to
+// price them: 1 = producer in the main loop, 2 = MFMAs, 4 = epilogue stores.  Outputs are then wrong.
+#ifdef STGCN_ABLATION
+#define STGCN_ABL(bit) ((abl & (bit)) != 0)
+#else
+#define STGCN_ABL(bit) false
+#endif
+
 constexpr int NP = 128;  // output pixels per workgroup (4 MFMA column blocks)
 constexpr int CC = 16;   // input channels per LDS chunk
 constexpr int W12P = 16; // padded row of the folded graph-conv matrix: 12 weights, bias, pad
@@ -302,7 +310,7 @@ template <int JPR, bool BF16OUT>
 __global__ __launch_bounds__(256) void stem_mfma_f32_kernel(
     const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ W12,
     const float4 *__restrict__ Wp, const float *__restrict__ shift, void *y, int C, int T, int V, int K,
-    int ROW) {
+    int ROW, int abl) {
     constexpr int CIN0 = 3, S = 3, F = 12;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -404,9 +412,10 @@ __global__ __launch_bounds__(256) void stem_mfma_f32_kernel(
                 n0 = wp[(size_t)(kidx + 1) * 128];
                 n1 = wp[(size_t)(kidx + 1) * 128 + 64];
             }
-            mfma_tap(acc, a0, a1, cur + k * V, cur + (k + 1 < K ? k + 1 : k) * V, off[0], off[1], off[2], off[3],
-                     ROW, bq);
-            if (more) {
+            if (!STGCN_ABL(2))
+                mfma_tap(acc, a0, a1, cur + k * V, cur + (k + 1 < K ? k + 1 : k) * V, off[0], off[1], off[2], off[3],
+                         ROW, bq);
+            if (more && !STGCN_ABL(1)) {
                 const int c_end = min(CC, (k + 1) * rpt);
                 for (int c = k * rpt; c < c_end; ++c) produce_row(nxt, c, (ch + 1) * CC + c);
             }
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(256) void stem_mfma_f32_kernel(
         }
         __syncthreads();
     }
-    epilogue_store<BF16OUT>(acc, g, shift, y, n, C, mb, lane, TV);
+    if (!STGCN_ABL(4)) epilogue_store<BF16OUT>(acc, g, shift, y, n, C, mb, lane, TV);
 }
 
 // fold the graph-conv linear stages into W12[C][W12P] (see agcn_expand.hip for the algebra)
@@ -610,7 +619,7 @@ int launch_stem(const float *x, const float *P, const void *prep, const float *t
     do {                                                                                                \
         STGCN_HIP_CHECK(allow_lds(stem_mfma_f32_kernel<J, B>, lds));                                    \
         hipLaunchKernelGGL((stem_mfma_f32_kernel<J, B>), grid, dim3(256), lds, st, x, P, W12, Wp, t_shift, \
-                           out, C, T, V, K, ROW);                                                       \
+                           out, C, T, V, K, ROW, ablate_mask());                                        \
     } while (0)
     if (jpr == 1) { if (bf16out) LAUNCH_STEM(1, true); else LAUNCH_STEM(1, false); }
     else if (jpr == 2) { if (bf16out) LAUNCH_STEM(2, true); else LAUNCH_STEM(2, false); }

@@ -11,7 +11,7 @@ import threading
 from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstgcn_hip.so")
+LIB_PATH = os.environ.get("STGCN_LIB") or os.path.join(_HERE, "libstgcn_hip.so")   # STGCN_LIB: diagnostic builds
 ABI_VERSION = 1
 
 # stgcn_math / flags (include/stgcn_hip.h)

@@ -35,15 +35,26 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, keep_temps: bool = False) -> str:
-    """Compile every HIP source for gfx950 and link the shared library; returns its path."""
+def build(force: bool = False, verbose: bool = False, keep_temps: bool = False, ablation: bool = False) -> str:
+    """Compile every HIP source for gfx950 and link the shared library; returns its path.
+
+    ``ablation=True`` builds the diagnostic library libstgcn_hip_abl.so (-DSTGCN_ABLATION: phases of the
+    big kernels can be switched off with env STGCN_ABLATE to price them; never loaded by the package
+    unless STGCN_LIB points at it).
+    """
+    if ablation:
+        return _build(LIB.replace(".so", "_abl.so"), "build_abl", ["-DSTGCN_ABLATION"], verbose, keep_temps)
     if not force and not _stale():
         return LIB
+    return _build(LIB, "build", [], verbose, keep_temps)
+
+
+def _build(lib_path, objsub, extra, verbose, keep_temps):
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, objsub)
     os.makedirs(objdir, exist_ok=True)
     common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE,
-              "-Wall", "-Wno-unused-function"]
+              "-Wall", "-Wno-unused-function"] + extra
     if keep_temps:
         common += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     objs = []
@@ -61,13 +72,14 @@ def build(force: bool = False, verbose: bool = False, keep_temps: bool = False) 
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose or keep_temps:
             sys.stdout.write(out)
-    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path] + objs
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose=True, keep_temps="--keep-temps" in sys.argv)
+    path = build(force="--force" in sys.argv, verbose=True, keep_temps="--keep-temps" in sys.argv,
+                 ablation="--ablation" in sys.argv)
     print("built", path)

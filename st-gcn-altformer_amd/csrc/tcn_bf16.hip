@@ -7,20 +7,25 @@
 //   STGCN_MATH_BF16   : operands rounded to bf16 (hi only), one MFMA per k-step.
 //
 // Same implicit GEMM as tcn_conv.hip (out[Cout x pixels] = Wp[Cout x Cin*K] * B[Cin*K x pixels], a
-// temporal tap = a flat shift by V pixels), different operand staging because the bf16 MFMA wants 8
+// temporal tap = a flat shift by V pixels); the operand staging differs because the bf16 MFMA wants 8
 // consecutive k (= 8 consecutive channels of one tap) per lane:
-//   LDS image   : [pixel][32 channels] bf16, 64 B per pixel, one image for hi and one for lo, per
-//                 channel chunk of 32 (two k-steps of 16), double buffered.  The 16-byte channel
-//                 group q of pixel p sits at p*64 + ((q ^ ((p>>2)&3)) << 4): a ds_read_b128 of 16
-//                 consecutive pixels then touches all 16 slots of the 256-B bank row (conflict-free).
-//   weights     : packed [mb][chunk][tap][k-step][hi|lo][lane][8 bf16] with the BN scale folded in
-//                 before the split; a lane streams 16 B per operand straight from L2, one tap ahead.
-//   workgroup   : 2*NPB threads; wave = (output-channel block of 32) x (half of the NPB pixels = 4
-//                 MFMA column blocks); the two waves of a SIMD share their weight fragments through L1.
-//   fused stem  : each thread owns one or two tile pixels, keeps their 12 graph-conv features in
-//                 registers and writes relu(W12.feat+b), split into hi/lo, for 8 channels at a time as
-//                 one ds_write_b128 per image, interleaved with the MFMAs of the current chunk; the
-//                 (C x 13) folded matrix is read through the scalar cache (wave-uniform).
+//   workgroup   : 256 threads = 4 waves as 2 (channel halves) x 2 (pixel halves); tile = 128 output
+//                 channels x 128 output pixels; a wave owns 2x2 MFMA blocks (64 channels x 64 pixels, 64
+//                 accumulator registers).  ~42 KB (V=22) of LDS keeps 2 workgroups per CU, so one
+//                 workgroup's prologue / epilogue / barriers hide under the other's MFMAs.
+//   LDS image   : [pixel][16 channels] bf16 = 32 B per pixel, one image for hi and one for lo, per
+//                 channel chunk of 16 (one k-step per tap), double buffered.  The 16-byte channel group h
+//                 of pixel p sits at p*32 + ((h ^ ((p>>3)&1)) << 4): a ds_read_b128 of 16 consecutive
+//                 pixels touches all 16 slots of the 256-B bank row (conflict-free).
+//   weights     : packed [mb][chunk][tap][hi|lo][lane][8 bf16] with the BN scale folded in before the
+//                 split; a lane streams 16 B per fragment straight from L2, two taps ahead (the two
+//                 pixel-half waves of a channel half read the same fragments -> L1 hits).
+//   producer    : the next chunk is produced while the current one is consumed, in the SAME basic block
+//                 as the MFMAs (tap loop fully unrolled for K = 9), two channels per tap, so the VALU work
+//                 issues in the shadow of the wave's own MFMAs instead of as a separate phase.
+//                 Fused stem: relu(W12 . feat + b) from the 12 graph-conv features each thread keeps in
+//                 registers for its 1-3 tile pixels (W12 is wave-uniform: scalar loads).
+//                 Stand-alone temporal conv: fp32 activations loaded from HBM/L2, coalesced along pixels.
 #include "common.h"
 
 namespace stgcn {
@@ -38,8 +43,10 @@ using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 #define STGCN_ABL(bit) false
 #endif
 
-constexpr int CCB = 32;   // input channels per LDS chunk (two 16-deep k-steps per tap)
-constexpr int PXB = 64;   // bytes per pixel row of one image
+constexpr int NPB = 128;  // output pixels per workgroup
+constexpr int NT = 256;   // threads per workgroup
+constexpr int CCB = 16;   // input channels per LDS chunk = one 16-deep k-step per tap
+constexpr int PXB = 32;   // bytes per pixel row of one image
 constexpr int W12P = 16;  // row of the folded graph-conv matrix: 12 weights, bias, pad
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {  // RNE; a in the low half
@@ -61,7 +68,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-__device__ __forceinline__ int lds_off(int p, int q) { return p * PXB + ((q ^ ((p >> 2) & 3)) << 4); }
+__device__ __forceinline__ int lds_off(int p, int h) { return p * PXB + ((h ^ ((p >> 3) & 1)) << 4); }
 
 template <bool BF16OUT>
 __device__ __forceinline__ void store_out(void *y, size_t idx, float v) {
@@ -69,8 +76,8 @@ __device__ __forceinline__ void store_out(void *y, size_t idx, float v) {
     else reinterpret_cast<float *>(y)[idx] = v;
 }
 
-// weight packing: Wp (bf16) index ((((mb*nch+ch)*K+tap)*2+kb)*2+img)*64+lane)*8+j
-//   o = mb*32 + (lane&31), c = ch*32 + kb*16 + 8*(lane>>5) + j, value = split(scale[o]*W[o][c][tap])[img]
+// weight packing: Wp (bf16) index (((((mb*nch+ch)*K+tap)*2+img)*64+lane)*8+j
+//   o = mb*32 + (lane&31), c = ch*16 + 8*(lane>>5) + j, value = split(scale[o]*W[o][c][tap])[img]
 __global__ void tcn_pack_bf16_kernel(const float *__restrict__ W, const float *__restrict__ scale,
                                      unsigned short *__restrict__ Wp, int Cin, int Cout, int K) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (weight, img)
@@ -80,15 +87,13 @@ __global__ void tcn_pack_bf16_kernel(const float *__restrict__ W, const float *_
     size_t r = e >> 9;
     const int img = (int)(r & 1);
     r >>= 1;
-    const int kb = (int)(r & 1);
-    r >>= 1;
     const int tap = (int)(r % K);
     r /= K;
     const int nch = Cin / CCB;
     const int ch = (int)(r % nch);
     const int mb = (int)(r / nch);
     const int o = mb * 32 + (lane & 31);
-    const int c = ch * CCB + kb * 16 + 8 * (lane >> 5) + j;
+    const int c = ch * CCB + 8 * (lane >> 5) + j;
     const float w = scale[o] * W[((size_t)o * Cin + c) * K + tap];
     const unsigned h = pack_bf16x2(w, 0.f) & 0xffffu;
     const unsigned l = pack_bf16x2(w - bf16_lo_to_f32(h), 0.f) & 0xffffu;
@@ -99,7 +104,6 @@ struct TileGeomB {
     int q0, q_last, t_first, span, origin;
 };
 
-template <int NPB>
 __device__ __forceinline__ TileGeomB tile_geom_b(int tile, int V, int K, int stride, int Tout) {
     TileGeomB g;
     g.q0 = tile * NPB;
@@ -111,59 +115,52 @@ __device__ __forceinline__ TileGeomB tile_geom_b(int tile, int V, int K, int str
     return g;
 }
 
-// B operands of one k-step for the wave's 4 pixel blocks
 template <int TERMS>
-struct BFrag {
-    uint4 hi[4];
-    uint4 lo[TERMS == 3 ? 4 : 1];
+struct Frag2 {  // operands of one k-step for 2 MFMA blocks: [block] hi (+ lo)
+    uint4 hi[2];
+    uint4 lo[TERMS == 3 ? 2 : 1];
 };
 
+// 12 (or 4) MFMAs of one k-step: 2 channel blocks x 2 pixel blocks
 template <int TERMS>
-__device__ __forceinline__ void load_bfrag(BFrag<TERMS> &b, const char *__restrict__ img_hi, int img_bytes,
-                                           const int (&addr)[4], int xr) {
+__device__ __forceinline__ void mfma_kstep_bf16(f32x16 (&acc)[2][2], const Frag2<TERMS> &a, const Frag2<TERMS> &b) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        b.hi[j] = *reinterpret_cast<const uint4 *>(img_hi + (addr[j] ^ xr));
-        if constexpr (TERMS == 3) b.lo[j] = *reinterpret_cast<const uint4 *>(img_hi + img_bytes + (addr[j] ^ xr));
-    }
-}
-
-template <int TERMS>
-__device__ __forceinline__ void mfma_kstep_bf16(f32x16 (&acc)[4], const uint4 &a_hi, const uint4 &a_lo,
-                                                const BFrag<TERMS> &b) {
-    const bf16x8 ah = __builtin_bit_cast(bf16x8, a_hi);
+    for (int m = 0; m < 2; ++m) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, a.hi[m]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi[j]);
-        if constexpr (TERMS == 3) {
-            const bf16x8 al = __builtin_bit_cast(bf16x8, a_lo);
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, b.lo[j]);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+        for (int n = 0; n < 2; ++n) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi[n]);
+            if constexpr (TERMS == 3) {
+                const bf16x8 al = __builtin_bit_cast(bf16x8, a.lo[m]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, b.lo[n]);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m][n], 0, 0, 0);
+            }
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m][n], 0, 0, 0);
         }
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
     }
 }
 
 // -----------------------------------------------------------------------------------------------
 // FUSED = false : x is the (N,Cin,T,V) fp32 input of the temporal conv
 // FUSED = true  : x is the (N,3,T,V) skeleton, P the attention matrices, W12 the folded graph conv
+// KT            : 9 = tap loop fully unrolled with the producer interleaved; 0 = any K (runtime loop)
 // -----------------------------------------------------------------------------------------------
-template <int NPB, int JPR, int TERMS, bool BF16OUT, bool FUSED>
-__global__ __launch_bounds__(2 * NPB) void tcn_mfma_bf16_kernel(
+template <int JPR, int TERMS, bool BF16OUT, bool FUSED, int KT>
+__global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
     const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ W12,
     const uint4 *__restrict__ Wp, const float *__restrict__ shift, void *y, int Cin, int Cout, int T, int V,
-    int K, int stride, int Tout, int ROWS /* pixel rows per image */, int abl) {
-    constexpr int NT = 2 * NPB;
+    int Krt, int stride, int Tout, int ROWS /* pixel rows per image */, int abl) {
     constexpr int CIN0 = 3, S = 3, F = 12;
+    const int K = KT ? KT : Krt;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int mb = blockIdx.y * 4 + (wave & 3);
-    const int nh = wave >> 2;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int mb0 = blockIdx.y * 4 + wm * 2;
     const int n = blockIdx.z;
-    const TileGeomB g = tile_geom_b<NPB>(blockIdx.x, V, K, stride, Tout);
+    const TileGeomB g = tile_geom_b(blockIdx.x, V, K, stride, Tout);
     const int TV = T * V;
     const int nch = Cin / CCB;
     const int img_bytes = ROWS * PXB;
@@ -171,23 +168,25 @@ __global__ __launch_bounds__(2 * NPB) void tcn_mfma_bf16_kernel(
     char *buf0 = smem_b;
     char *buf1 = smem_b + buf_bytes;
 
-    // tile columns owned by this thread: column j <-> flat input pixel origin + j
-    int jcol[JPR];
-    bool jok[JPR], jwr[JPR];
+    // tile columns owned by this thread: column j <-> flat input pixel origin + j.  Columns past the tile's
+    // span are redirected to the spare row ROWS-1 (a dump row that is never read) so stores need no branch.
+    int jcol[JPR], jdst[JPR];
+    bool jok[JPR];
 #pragma unroll
     for (int jj = 0; jj < JPR; ++jj) {
         jcol[jj] = tid + jj * NT;
         const int gi = g.origin + jcol[jj];
-        jwr[jj] = jcol[jj] < g.span;
-        jok[jj] = jwr[jj] && gi >= 0 && gi < TV;
+        const bool wr = jcol[jj] < g.span;
+        jok[jj] = wr && gi >= 0 && gi < TV;
+        jdst[jj] = wr ? jcol[jj] : ROWS - 1;
     }
 
     // ---- producer state ------------------------------------------------------------------
     float feat[FUSED ? JPR : 1][F];
-    float pre8[FUSED ? 1 : JPR][8];  // !FUSED: one 8-channel unit of this thread's pixels, in flight from HBM/L2
+    float pv[JPR][8];  // 8 channels of the unit being assembled (fused: computed; else: loaded)
     const float *xn = x + (size_t)n * (FUSED ? CIN0 : Cin) * TV;
     if constexpr (FUSED) {
-        float *Ps = reinterpret_cast<float *>(buf1);  // [S][V][V]   (buf1 is free until chunk 1 is produced)
+        float *Ps = reinterpret_cast<float *>(buf1);  // [S][V][V]   (the buf1 region is free until chunk 1)
         float *Xs = Ps + S * V * V;                   // [CIN0][span]
         const float *Pn = P + (size_t)n * S * V * V;
         for (int e = tid; e < S * V * V; e += NT) Ps[e] = Pn[e];
@@ -204,16 +203,19 @@ __global__ __launch_bounds__(2 * NPB) void tcn_mfma_bf16_kernel(
             if (jok[jj]) {
                 const int j = jcol[jj];
                 const int fr = j / V, w = j - fr * V;
+                const float *xr = Xs + fr * V;
+                const float *pc = Ps + w;
+#pragma unroll 2
                 for (int v = 0; v < V; ++v) {
                     float xv[CIN0];
 #pragma unroll
-                    for (int k = 0; k < CIN0; ++k) xv[k] = Xs[k * g.span + fr * V + v];
+                    for (int k = 0; k < CIN0; ++k) xv[k] = xr[k * g.span + v];
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        const float pv = Ps[(s * V + v) * V + w];
+                        const float pw = pc[(s * V + v) * V];
 #pragma unroll
                         for (int k = 0; k < CIN0; ++k)
-                            feat[jj][s * CIN0 + k] = fmaf(xv[k], pv, feat[jj][s * CIN0 + k]);
+                            feat[jj][s * CIN0 + k] = fmaf(xv[k], pw, feat[jj][s * CIN0 + k]);
                     }
                 }
 #pragma unroll
@@ -222,191 +224,226 @@ __global__ __launch_bounds__(2 * NPB) void tcn_mfma_bf16_kernel(
         }
     }
 
-    // one 8-channel group (unit u of chunk ch) of this thread's pixels -> LDS images of `buf`
-    auto produce_unit = [&](char *buf, int ch, int u) {
+    // value of channel c (chunk ch) at this thread's pixels -> pv[jj][slot]   (fused path)
+    auto compute_channel = [&](int ch, int c, int slot) {
+        if constexpr (FUSED) {
+            const int o = min(ch * CCB + c, Cin - 1);      // clamp: the pass after the last chunk is discarded
+            const float *wr = W12 + (size_t)o * W12P;      // wave-uniform address: scalar loads
 #pragma unroll
-        for (int jj = 0; jj < JPR; ++jj) {
-            float v[8];
-            if constexpr (FUSED) {
+            for (int jj = 0; jj < JPR; ++jj) {
+                float a = wr[F];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float *wr = W12 + (size_t)(ch * CCB + u * 8 + i) * W12P;  // wave-uniform: scalar loads
-                    float a = wr[F];
-#pragma unroll
-                    for (int f = 0; f < F; ++f) a = fmaf(wr[f], feat[jj][f], a);
-                    v[i] = jok[jj] ? fmaxf(a, 0.f) : 0.f;  // outside the clip the conv sees zero padding
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = pre8[jj][i];
-            }
-            if (jwr[jj]) {
-                uint4 hi, lo;
-                split8(v, hi, lo);
-                const int off = lds_off(jcol[jj], u);
-                *reinterpret_cast<uint4 *>(buf + off) = hi;
-                if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(buf + img_bytes + off) = lo;
+                for (int f = 0; f < F; ++f) a = fmaf(wr[f], feat[jj][f], a);
+                pv[jj][slot] = jok[jj] ? fmaxf(a, 0.f) : 0.f;  // outside the clip the conv sees zero padding
             }
         }
     };
-    auto load_unit = [&](int ch, int u) {  // !FUSED: 8 channels of this thread's pixels, coalesced along pixels
+    // 8 channels (unit u of chunk ch) of this thread's pixels, straight from global memory (stand-alone path)
+    auto load_unit = [&](int ch, int u) {
         if constexpr (!FUSED) {
+            const int c0 = min(ch, nch - 1) * CCB + u * 8;
 #pragma unroll
             for (int jj = 0; jj < JPR; ++jj)
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    pre8[jj][i] = jok[jj] ? xn[(size_t)(ch * CCB + u * 8 + i) * TV + g.origin + jcol[jj]] : 0.f;
+                    pv[jj][i] = jok[jj] ? xn[(size_t)(c0 + i) * TV + g.origin + jcol[jj]] : 0.f;
         }
+    };
+    // split pv into hi/lo and store it as unit u of `buf`
+    auto store_unit = [&](char *buf, int u) {
+#pragma unroll
+        for (int jj = 0; jj < JPR; ++jj) {
+            uint4 hi, lo;
+            split8(pv[jj], hi, lo);
+            const int off = lds_off(jdst[jj], u);
+            *reinterpret_cast<uint4 *>(buf + off) = hi;
+            if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(buf + img_bytes + off) = lo;
+        }
+    };
+    auto produce_unit_now = [&](char *buf, int ch, int u) {  // whole unit at once (prologue / generic-K path)
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) compute_channel(ch, u * 8 + i, i);
+        } else {
+            load_unit(ch, u);
+        }
+        store_unit(buf, u);
     };
 
     // ---- consumer state ------------------------------------------------------------------
-    // pixel row (tile-local) of each of the wave's 4 column blocks at tap 0
-    int prow[4];
+    int prow[2];  // tile-local pixel row of the wave's 2 column blocks at tap 0
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int q = g.q0 + nh * 128 + j * 32 + (lane & 31);
+    for (int j = 0; j < 2; ++j) {
+        int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
         q = min(q, g.q_last);
         const int t = q / V, v = q - t * V;
         prow[j] = (t - g.t_first) * stride * V + v;
     }
     const int h = lane >> 5;
-    f32x16 acc[4];
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
-    for (int u = 0; u < 4; ++u) {
-        load_unit(0, u);
-        produce_unit(buf0, 0, u);
-    }
-    __syncthreads();  // chunk 0 visible; (fused) every wave is done with Ps/Xs in buf1
+    produce_unit_now(buf0, 0, 0);
+    produce_unit_now(buf0, 0, 1);
+    __syncthreads();  // chunk 0 visible; (fused) every wave is done with Ps/Xs in the buf1 region
 
-    // A fragments: [kb*2 + img], one tap ahead
-    const uint4 *wp = Wp + (size_t)mb * nch * K * 4 * 64 + lane;  // + (kidx*4 + kb*2 + img)*64
+    // weight fragments: [m].hi/.lo of flat k index kidx = ch*K + tap at wpm[m][(kidx*2 + img)*64]
     const int nk = nch * K;
-    uint4 aq[4];
+    const uint4 *wpm0 = Wp + (size_t)(mb0 + 0) * nk * 2 * 64 + lane;
+    const uint4 *wpm1 = Wp + (size_t)(mb0 + 1) * nk * 2 * 64 + lane;
+    auto load_a = [&](Frag2<TERMS> &a, int kidx) {
+        const int kc = min(kidx, nk - 1);  // past the end: re-read the last fragment (discarded)
+        if (STGCN_ABL(16)) return;
+        a.hi[0] = wpm0[(size_t)kc * 128];
+        a.hi[1] = wpm1[(size_t)kc * 128];
+        if constexpr (TERMS == 3) {
+            a.lo[0] = wpm0[(size_t)kc * 128 + 64];
+            a.lo[1] = wpm1[(size_t)kc * 128 + 64];
+        }
+    };
+    auto load_b = [&](Frag2<TERMS> &b, const char *buf, int tap) {
+        if (STGCN_ABL(8)) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) aq[i] = (TERMS == 3 || !(i & 1)) ? wp[i * 64] : make_uint4(0, 0, 0, 0);
-    const int upt = (4 + K - 1) / K;
+        for (int j = 0; j < 2; ++j) {
+            const int off = lds_off(prow[j] + tap * V, h);
+            b.hi[j] = *reinterpret_cast<const uint4 *>(buf + off);
+            if constexpr (TERMS == 3) b.lo[j] = *reinterpret_cast<const uint4 *>(buf + img_bytes + off);
+        }
+    };
+
+    Frag2<TERMS> a0 = {}, a1 = {}, a2 = {};  // taps kidx, kidx+1, kidx+2
+    load_a(a0, 0);
+    load_a(a1, 1);
     int kidx = 0;
     for (int ch = 0; ch < nch; ++ch) {
         const char *cur = (ch & 1) ? buf1 : buf0;
         char *nxt = (ch & 1) ? buf0 : buf1;
-        const bool more = ch + 1 < nch;
-        int addr[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) addr[j] = lds_off(prow[j], h);
-        BFrag<TERMS> bq;
-        load_bfrag<TERMS>(bq, cur, img_bytes, addr, 0);
-        for (int k = 0; k < K; ++k, ++kidx) {
-            uint4 an[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) an[i] = aq[i];
-            if (kidx + 1 < nk && !STGCN_ABL(16)) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (TERMS == 3 || !(i & 1)) an[i] = wp[((size_t)(kidx + 1) * 4 + i) * 64];
+        Frag2<TERMS> b0 = {}, b1 = {};
+        load_b(b0, cur, 0);
+        if constexpr (KT == 9) {
+            // ---- fully unrolled: one basic block per chunk, producer slices between the MFMAs ----
+#define STGCN_TAP(TAP)                                                                                   \
+    do {                                                                                                 \
+        load_a(a2, kidx + 2);                                                                            \
+        load_b(b1, cur, (TAP) + 1 < 9 ? (TAP) + 1 : (TAP));                                              \
+        if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a0, b0);                                          \
+        if (!STGCN_ABL(1)) {                                                                             \
+            if constexpr (FUSED) {                                                                       \
+                if ((TAP) < 8) {                                                                         \
+                    compute_channel(ch + 1, 2 * (TAP), (2 * (TAP)) & 7);                                 \
+                    compute_channel(ch + 1, 2 * (TAP) + 1, (2 * (TAP) + 1) & 7);                         \
+                }                                                                                        \
+            } else {                                                                                     \
+                if ((TAP) == 0) load_unit(ch + 1, 0);                                                    \
+            }                                                                                            \
+            if ((TAP) == 3) {                                                                            \
+                store_unit(nxt, 0);                                                                      \
+                if constexpr (!FUSED) load_unit(ch + 1, 1);                                              \
+            }                                                                                            \
+            if ((TAP) == 7) store_unit(nxt, 1);                                                          \
+        }                                                                                                \
+        a0 = a1;                                                                                         \
+        a1 = a2;                                                                                         \
+        b0 = b1;                                                                                         \
+        ++kidx;                                                                                          \
+    } while (0)
+            STGCN_TAP(0);
+            STGCN_TAP(1);
+            STGCN_TAP(2);
+            STGCN_TAP(3);
+            STGCN_TAP(4);
+            STGCN_TAP(5);
+            STGCN_TAP(6);
+            STGCN_TAP(7);
+            STGCN_TAP(8);
+#undef STGCN_TAP
+        } else {
+            for (int k = 0; k < K; ++k, ++kidx) {
+                load_a(a2, kidx + 2);
+                load_b(b1, cur, k + 1 < K ? k + 1 : k);
+                if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a0, b0);
+                a0 = a1;
+                a1 = a2;
+                b0 = b1;
             }
-            // k-step 0 of this tap: fetch k-step 1 (same pixels, channel groups q^2 -> address ^ 32)
-            BFrag<TERMS> bn = bq;
-            if (!STGCN_ABL(8)) load_bfrag<TERMS>(bn, cur, img_bytes, addr, 32);
-            if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, aq[0], aq[1], bq);
-            __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 8 : 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TERMS == 3 ? 12 : 4, 0);
-            // k-step 1: fetch k-step 0 of the next tap (V pixel rows further; same tap again at the end)
-            const int kn = (k + 1 < K) ? k + 1 : k;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) addr[j] = lds_off(prow[j] + kn * V, h);
-            if (!STGCN_ABL(8)) load_bfrag<TERMS>(bq, cur, img_bytes, addr, 0);
-            if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, aq[2], aq[3], bn);
-            __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 8 : 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TERMS == 3 ? 12 : 4, 0);
-            if (more && !STGCN_ABL(1)) {
-                if (K >= 8) {  // unit u of the next chunk: loads issued at tap 2u, split + LDS store at tap 2u+1
-                    if ((k >> 1) < 4) {
-                        if (k & 1) produce_unit(nxt, ch + 1, k >> 1);
-                        else load_unit(ch + 1, k >> 1);
-                    }
-                } else {
-                    const int u_end = min(4, (k + 1) * upt);
-                    for (int u = k * upt; u < u_end; ++u) {
-                        load_unit(ch + 1, u);
-                        produce_unit(nxt, ch + 1, u);
-                    }
-                }
+            if (ch + 1 < nch) {
+                produce_unit_now(nxt, ch + 1, 0);
+                produce_unit_now(nxt, ch + 1, 1);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) aq[i] = an[i];
         }
         __syncthreads();
     }
 
     // epilogue: D[row = channel][col = pixel], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int ppc = Tout * V;
     if (STGCN_ABL(4)) return;
+    const int ppc = Tout * V;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int o = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const float sh = shift[o];
-        const size_t base = ((size_t)n * Cout + o) * ppc;
+    for (int m = 0; m < 2; ++m) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = g.q0 + nh * 128 + j * 32 + (lane & 31);
-            if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[j][r] + sh, 0.f));
+        for (int r = 0; r < 16; ++r) {
+            const int o = (mb0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float sh = shift[o];
+            const size_t base = ((size_t)n * Cout + o) * ppc;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
+                if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[m][j][r] + sh, 0.f));
+            }
         }
     }
 }
 
-// pixel rows per LDS image for the widest tile of a launch
-inline int rows_needed(int NPB, int V, int K, int stride, int Tout) {
+// pixel rows per LDS image for the widest tile of a launch, plus one spare "dump" row
+inline int rows_needed(int V, int K, int stride, int Tout) {
     int dt = ceil_div(NPB - 1, V);
     if (dt > Tout - 1) dt = Tout - 1;
-    return (dt * stride + K) * V;
+    return (dt * stride + K) * V + 1;
 }
 
 struct Bf16Plan {
-    int npb = 0, jpr = 0, rows = 0;
+    int jpr = 0, rows = 0;
     size_t lds = 0;
 };
 
 inline bool plan_bf16(int Cin, int Cout, int V, int K, int stride, int Tout, int terms, bool fused, Bf16Plan &pl) {
     if (Cin % CCB != 0 || Cout % 128 != 0) return false;
-    const int cands[2] = {256, 128};
-    for (int ci = 0; ci < 2; ++ci) {
-        const int npb = cands[ci];
-        const int rows = rows_needed(npb, V, K, stride, Tout);
-        const int jpr = ceil_div(rows, 2 * npb);
-        if (jpr > (npb == 128 ? 3 : 2)) continue;
-        const size_t buf = (size_t)rows * PXB * (terms == 3 ? 2 : 1);
-        const size_t lds = 2 * buf;
-        if (lds > (size_t)kLdsBytes) continue;
-        if (fused && ((size_t)3 * V * V + (size_t)3 * rows) * 4 > buf) continue;  // Ps + Xs alias buf1
-        // prefer one big tile per CU only when it still leaves the smaller geometry no better fit
-        pl.npb = npb;
-        pl.jpr = jpr;
-        pl.rows = rows;
-        pl.lds = lds;
-        return true;
+    const int rows = rows_needed(V, K, stride, Tout);
+    const int jpr = ceil_div(rows - 1, NT);
+    if (jpr > 3) return false;
+    const size_t buf = (size_t)rows * PXB * (terms == 3 ? 2 : 1);
+    size_t second = buf;
+    if (fused) {  // Ps + Xs live where buf1 starts until chunk 1 is produced
+        const size_t px = ((size_t)3 * V * V + (size_t)3 * rows) * 4;
+        if (px > second) second = px;
     }
-    return false;
+    const size_t lds = buf + second;
+    if (lds > (size_t)kLdsBytes) return false;
+    pl.jpr = jpr;
+    pl.rows = rows;
+    pl.lds = lds;
+    return true;
 }
 
-template <int NPB, int JPR, int TERMS, bool FUSED>
+template <int JPR, int TERMS, bool FUSED, int KT>
 int launch_variant(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y,
                    int N, int Cin, int Cout, int T, int V, int K, int stride, int Tout, const Bf16Plan &pl,
                    bool bf16out, hipStream_t st) {
     const dim3 grid(ceil_div(Tout * V, NPB), Cout / 128, N);
     if (bf16out) {
-        auto kern = tcn_mfma_bf16_kernel<NPB, JPR, TERMS, true, FUSED>;
+        auto kern = tcn_mfma_bf16_kernel<JPR, TERMS, true, FUSED, KT>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
-        hipLaunchKernelGGL(kern, grid, dim3(2 * NPB), pl.lds, st, x, P, W12, Wp, shift, y, Cin, Cout, T, V, K, stride,
-                           Tout, pl.rows, ablate_mask());
+        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, Cin, Cout, T, V, K, stride, Tout,
+                           pl.rows, ablate_mask());
     } else {
-        auto kern = tcn_mfma_bf16_kernel<NPB, JPR, TERMS, false, FUSED>;
+        auto kern = tcn_mfma_bf16_kernel<JPR, TERMS, false, FUSED, KT>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
-        hipLaunchKernelGGL(kern, grid, dim3(2 * NPB), pl.lds, st, x, P, W12, Wp, shift, y, Cin, Cout, T, V, K, stride,
-                           Tout, pl.rows, ablate_mask());
+        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, Cin, Cout, T, V, K, stride, Tout,
+                           pl.rows, ablate_mask());
     }
     STGCN_LAUNCH_CHECK("tcn_mfma_bf16_kernel");
     return STGCN_OK;
@@ -416,14 +453,17 @@ template <int TERMS, bool FUSED>
 int dispatch(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y, int N,
              int Cin, int Cout, int T, int V, int K, int stride, int Tout, const Bf16Plan &pl, bool bf16out,
              hipStream_t st) {
-#define GO(NPB, JPR)                                                                                         \
-    return launch_variant<NPB, JPR, TERMS, FUSED>(x, P, W12, Wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, \
-                                                  pl, bf16out, st)
-    if (pl.npb == 256 && pl.jpr == 1) GO(256, 1);
-    if (pl.npb == 256 && pl.jpr == 2) GO(256, 2);
-    if (pl.npb == 128 && pl.jpr == 1) GO(128, 1);
-    if (pl.npb == 128 && pl.jpr == 2) GO(128, 2);
-    GO(128, 3);
+#define GO(JPR, KT)                                                                                             \
+    return launch_variant<JPR, TERMS, FUSED, KT>(x, P, W12, Wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, \
+                                                 bf16out, st)
+    if (K == 9) {
+        if (pl.jpr == 1) GO(1, 9);
+        if (pl.jpr == 2) GO(2, 9);
+        GO(3, 9);
+    }
+    if (pl.jpr == 1) GO(1, 0);
+    if (pl.jpr == 2) GO(2, 0);
+    GO(3, 0);
 #undef GO
 }
 
@@ -460,7 +500,7 @@ int launch_tcn_bf16(const float *x, const float *P, const float *W12, const void
     Bf16Plan pl;
     if (Tout < 1 || !plan_bf16(Cin, Cout, V, K, stride, Tout, terms, fused, pl))
         return fail(STGCN_ERR_UNSUPPORTED,
-                    "bf16 MFMA kernel does not cover Cin=%d Cout=%d V=%d K=%d stride=%d T=%d (needs Cin%%32==0, "
+                    "bf16 MFMA kernel does not cover Cin=%d Cout=%d V=%d K=%d stride=%d T=%d (needs Cin%%16==0, "
                     "Cout%%128==0, tile rows that fit LDS)", Cin, Cout, V, K, stride, T);
     const uint4 *wp = (const uint4 *)Wp;
     if (fused) {

@@ -398,6 +398,280 @@ __global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
     }
 }
 
+
+// -----------------------------------------------------------------------------------------------
+// Fused stem on the bf16 matrix cores.  Same consumer as above; the producer is itself an MFMA:
+//   Fs   : LDS tile [tile pixel][16] fp32 = the 12 graph-conv features of the pixel, a validity flag
+//          (1 inside the clip, else the whole row is 0 -> the conv sees its zero padding), 3 zeros.
+//   y    = relu(W12[16 ch x 16] . Fs^T[16 x 16 px])  by 4 x v_mfma_f32_16x16x4_f32 (exact fp32) per
+//          16-pixel block; the D fragment (lane = pixel, 4 consecutive channels per lane group) is
+//          split into bf16 hi/lo and stored as 8 bytes per image.  One block per wave per tap, in the
+//          same basic block as the 12 consumer MFMAs: ~25 VALU per block instead of ~60 FMAs per tap.
+// PB = producer blocks per wave per chunk (rows/16/4 rounded up), KT as above.
+// -----------------------------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int PB, int TERMS, bool BF16OUT, int KT>
+__global__ __launch_bounds__(NT) void stem_mfma_bf16_kernel(
+    const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ W12,
+    const uint4 *__restrict__ Wp, const float *__restrict__ shift, void *y, int C, int T, int V, int Krt,
+    int ROWS /* pixel rows per image, multiple of 16 */, int abl) {
+    constexpr int CIN0 = 3, S = 3, F = 12;
+    const int K = KT ? KT : Krt;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int mb0 = blockIdx.y * 4 + wm * 2;
+    const int n = blockIdx.z;
+    const TileGeomB g = tile_geom_b(blockIdx.x, V, K, 1, T);
+    const int TV = T * V;
+    const int nch = C / CCB;
+    const int img_bytes = ROWS * PXB;
+    const int buf_bytes = img_bytes * (TERMS == 3 ? 2 : 1);
+    char *buf0 = smem_b;
+    char *buf1 = smem_b + buf_bytes;
+    float *Fs = reinterpret_cast<float *>(smem_b + 2 * buf_bytes);  // [ROWS][16]
+    const int nblk = (g.span + 15) >> 4;                            // 16-pixel producer blocks of this tile
+
+    // ---- prologue: stage P and the skeleton tile, build the feature tile ---------------------
+    {
+        float *Ps = reinterpret_cast<float *>(smem_b);  // [S][V][V]  (buf0/buf1 are free until chunk 0 is produced)
+        float *Xs = Ps + S * V * V;                     // [CIN0][span]
+        const float *Pn = P + (size_t)n * S * V * V;
+        const float *xn = x + (size_t)n * CIN0 * TV;
+        for (int e = tid; e < S * V * V; e += NT) Ps[e] = Pn[e];
+        for (int e = tid; e < CIN0 * g.span; e += NT) {
+            const int k = e / g.span, j = e - k * g.span;
+            const int gi = g.origin + j;
+            Xs[e] = (gi >= 0 && gi < TV) ? xn[(size_t)k * TV + gi] : 0.f;
+        }
+        __syncthreads();
+        for (int j = tid; j < ROWS; j += NT) {
+            float feat[16];
+#pragma unroll
+            for (int f = 0; f < 16; ++f) feat[f] = 0.f;
+            const int gi = g.origin + j;
+            if (j < g.span && gi >= 0 && gi < TV) {
+                const int fr = j / V, w = j - fr * V;
+                const float *xr = Xs + fr * V;
+                const float *pc = Ps + w;
+#pragma unroll 2
+                for (int v = 0; v < V; ++v) {
+                    float xv[CIN0];
+#pragma unroll
+                    for (int k = 0; k < CIN0; ++k) xv[k] = xr[k * g.span + v];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const float pw = pc[(s * V + v) * V];
+#pragma unroll
+                        for (int k = 0; k < CIN0; ++k) feat[s * CIN0 + k] = fmaf(xv[k], pw, feat[s * CIN0 + k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < CIN0; ++k) feat[S * CIN0 + k] = Xs[k * g.span + j];
+                feat[F] = 1.f;  // multiplies the folded bias; 0 outside the clip
+            }
+            float4 *dst = reinterpret_cast<float4 *>(Fs + (size_t)j * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = make_float4(feat[4 * q], feat[4 * q + 1], feat[4 * q + 2], feat[4 * q + 3]);
+        }
+        __syncthreads();  // Fs complete; Ps/Xs dead -> buf0/buf1 may be overwritten
+    }
+
+    // ---- producer: one 16-pixel block of chunk `ch` -> hi/lo images of `buf` -------------------
+    const int pl = lane & 15, pg = lane >> 4;  // pixel within block / channel group (4 channels) = k quarter
+    auto load_w12 = [&](int ch) {              // A operand of the producer: W12[ch*16 + pl][4*pg .. 4*pg+3]
+        const int o = min(ch, nch - 1) * CCB + pl;
+        return *reinterpret_cast<const float4 *>(W12 + (size_t)o * W12P + 4 * pg);
+    };
+    auto produce_block = [&](char *buf, const float4 &wa, int bi) {
+        const int p = bi * 16 + pl;
+        const float4 fb = *reinterpret_cast<const float4 *>(Fs + (size_t)p * 16 + 4 * pg);
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, fb.x, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, fb.y, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, fb.z, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, fb.w, d, 0, 0, 0);
+        // lane holds channels 4*pg .. 4*pg+3 of pixel p
+        const float v0 = fmaxf(d[0], 0.f), v1 = fmaxf(d[1], 0.f), v2 = fmaxf(d[2], 0.f), v3 = fmaxf(d[3], 0.f);
+        const unsigned h0 = pack_bf16x2(v0, v1), h1 = pack_bf16x2(v2, v3);
+        const int off = lds_off(p, pg >> 1) + (pg & 1) * 8;
+        *reinterpret_cast<uint2 *>(buf + off) = make_uint2(h0, h1);
+        if constexpr (TERMS == 3) {
+            const unsigned l0 = pack_bf16x2(v0 - bf16_lo_to_f32(h0), v1 - bf16_hi_to_f32(h0));
+            const unsigned l1 = pack_bf16x2(v2 - bf16_lo_to_f32(h1), v3 - bf16_hi_to_f32(h1));
+            *reinterpret_cast<uint2 *>(buf + img_bytes + off) = make_uint2(l0, l1);
+        }
+    };
+
+    // ---- consumer state ------------------------------------------------------------------
+    int prow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
+        q = min(q, g.q_last);
+        const int t = q / V, v = q - t * V;
+        prow[j] = (t - g.t_first) * V + v;
+    }
+    const int h = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+    float4 wcur = load_w12(0);
+    for (int b = wave; b < nblk; b += 4) produce_block(buf0, wcur, b);
+    float4 wnext = load_w12(1);
+    __syncthreads();  // chunk 0 visible
+
+    const int nk = nch * K;
+    const uint4 *wpm0 = Wp + (size_t)(mb0 + 0) * nk * 2 * 64 + lane;
+    const uint4 *wpm1 = Wp + (size_t)(mb0 + 1) * nk * 2 * 64 + lane;
+    auto load_a = [&](Frag2<TERMS> &a, int kidx) {
+        const int kc = min(kidx, nk - 1);
+        if (STGCN_ABL(16)) return;
+        a.hi[0] = wpm0[(size_t)kc * 128];
+        a.hi[1] = wpm1[(size_t)kc * 128];
+        if constexpr (TERMS == 3) {
+            a.lo[0] = wpm0[(size_t)kc * 128 + 64];
+            a.lo[1] = wpm1[(size_t)kc * 128 + 64];
+        }
+    };
+    auto load_b = [&](Frag2<TERMS> &b, const char *buf, int tap) {
+        if (STGCN_ABL(8)) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int off = lds_off(prow[j] + tap * V, h);
+            b.hi[j] = *reinterpret_cast<const uint4 *>(buf + off);
+            if constexpr (TERMS == 3) b.lo[j] = *reinterpret_cast<const uint4 *>(buf + img_bytes + off);
+        }
+    };
+
+    Frag2<TERMS> a0 = {}, a1 = {}, a2 = {};
+    load_a(a0, 0);
+    load_a(a1, 1);
+    int kidx = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const char *cur = (ch & 1) ? buf1 : buf0;
+        char *nxt = (ch & 1) ? buf0 : buf1;
+        wcur = wnext;                 // W12 rows of chunk ch+1
+        wnext = load_w12(ch + 2);
+        Frag2<TERMS> b0 = {}, b1 = {};
+        load_b(b0, cur, 0);
+        if constexpr (KT == 9) {
+#define STGCN_TAP(TAP)                                                                                  \
+    do {                                                                                                \
+        load_a(a2, kidx + 2);                                                                           \
+        load_b(b1, cur, (TAP) + 1 < 9 ? (TAP) + 1 : (TAP));                                             \
+        if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a0, b0);                                         \
+        if ((TAP) < PB && !STGCN_ABL(1)) produce_block(nxt, wcur, min(wave + 4 * (TAP), nblk - 1));     \
+        a0 = a1;                                                                                        \
+        a1 = a2;                                                                                        \
+        b0 = b1;                                                                                        \
+        ++kidx;                                                                                         \
+    } while (0)
+            STGCN_TAP(0);
+            STGCN_TAP(1);
+            STGCN_TAP(2);
+            STGCN_TAP(3);
+            STGCN_TAP(4);
+            STGCN_TAP(5);
+            STGCN_TAP(6);
+            STGCN_TAP(7);
+            STGCN_TAP(8);
+#undef STGCN_TAP
+        } else {
+            for (int k = 0; k < K; ++k, ++kidx) {
+                load_a(a2, kidx + 2);
+                load_b(b1, cur, k + 1 < K ? k + 1 : k);
+                if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a0, b0);
+                a0 = a1;
+                a1 = a2;
+                b0 = b1;
+            }
+            if (ch + 1 < nch)
+                for (int b = wave; b < nblk; b += 4) produce_block(nxt, wcur, b);
+        }
+        __syncthreads();
+    }
+
+    if (STGCN_ABL(4)) return;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = (mb0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float sh = shift[o];
+            const size_t base = ((size_t)n * C + o) * TV;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
+                if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[m][j][r] + sh, 0.f));
+            }
+        }
+    }
+}
+
+struct StemPlan {
+    int pb = 0, rows = 0;
+    size_t lds = 0;
+};
+
+inline bool plan_stem_bf16(int C, int V, int K, int T, int terms, StemPlan &pl) {
+    if (C % CCB != 0 || C % 128 != 0) return false;
+    int dt = ceil_div(NPB - 1, V);
+    if (dt > T - 1) dt = T - 1;
+    const int span = (dt + K) * V;
+    const int rows = (span + 15) / 16 * 16;
+    const int pb = ceil_div(rows / 16, 4);
+    if (K == 9 ? pb > 9 : false) return false;  // unrolled path: at most one producer block per tap
+    const size_t buf = (size_t)rows * PXB * (terms == 3 ? 2 : 1);
+    const size_t fs = (size_t)rows * 64;
+    const size_t px = ((size_t)3 * V * V + (size_t)3 * span) * 4;  // Ps + Xs alias the two image buffers
+    if (px > 2 * buf) return false;
+    const size_t lds = 2 * buf + fs;
+    if (lds > (size_t)kLdsBytes) return false;
+    pl.pb = pb;
+    pl.rows = rows;
+    pl.lds = lds;
+    return true;
+}
+
+template <int PB, int TERMS, int KT>
+int launch_stem_variant(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y,
+                        int N, int C, int T, int V, int K, const StemPlan &pl, bool bf16out, hipStream_t st) {
+    const dim3 grid(ceil_div(T * V, NPB), C / 128, N);
+    if (bf16out) {
+        auto kern = stem_mfma_bf16_kernel<PB, TERMS, true, KT>;
+        STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
+        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, C, T, V, K, pl.rows, ablate_mask());
+    } else {
+        auto kern = stem_mfma_bf16_kernel<PB, TERMS, false, KT>;
+        STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
+        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, C, T, V, K, pl.rows, ablate_mask());
+    }
+    STGCN_LAUNCH_CHECK("stem_mfma_bf16_kernel");
+    return STGCN_OK;
+}
+
+template <int TERMS>
+int dispatch_stem(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y, int N,
+                  int C, int T, int V, int K, const StemPlan &pl, bool bf16out, hipStream_t st) {
+#define GO(PB, KT) return launch_stem_variant<PB, TERMS, KT>(x, P, W12, Wp, shift, y, N, C, T, V, K, pl, bf16out, st)
+    if (K == 9) {
+        if (pl.pb <= 3) GO(3, 9);
+        if (pl.pb <= 6) GO(6, 9);
+        GO(9, 9);
+    }
+    GO(9, 0);
+#undef GO
+}
+
 // pixel rows per LDS image for the widest tile of a launch, plus one spare "dump" row
 inline int rows_needed(int V, int K, int stride, int Tout) {
     int dt = ceil_div(NPB - 1, V);
@@ -450,7 +724,7 @@ int launch_variant(const float *x, const float *P, const float *W12, const uint4
 }
 
 template <int TERMS, bool FUSED>
-int dispatch(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y, int N,
+int dispatch_tcn(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y, int N,
              int Cin, int Cout, int T, int V, int K, int stride, int Tout, const Bf16Plan &pl, bool bf16out,
              hipStream_t st) {
 #define GO(JPR, KT)                                                                                             \
@@ -474,8 +748,13 @@ bool bf16_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned
     if (math != STGCN_MATH_BF16X3 && math != STGCN_MATH_BF16) return false;
     const int Tout = (T + 2 * ((K - 1) / 2) - K) / stride + 1;
     if (Tout < 1) return false;
+    const int terms = math == STGCN_MATH_BF16X3 ? 3 : 1;
+    if (fused) {
+        StemPlan sp;
+        return Cin == Cout && stride == 1 && plan_stem_bf16(Cin, V, K, T, terms, sp);
+    }
     Bf16Plan pl;
-    return plan_bf16(Cin, Cout, V, K, stride, Tout, math == STGCN_MATH_BF16X3 ? 3 : 1, fused, pl);
+    return plan_bf16(Cin, Cout, V, K, stride, Tout, terms, false, pl);
 }
 
 bool bf16_packs(int Cin, int Cout, unsigned math) {
@@ -497,18 +776,21 @@ int launch_tcn_bf16(const float *x, const float *P, const float *W12, const void
     const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
     const int terms = math == STGCN_MATH_BF16X3 ? 3 : 1;
     const int Tout = (T + 2 * ((K - 1) / 2) - K) / stride + 1;
+    if (fused) {
+        StemPlan sp;
+        if (Cin != Cout || stride != 1 || !plan_stem_bf16(Cin, V, K, T, terms, sp))
+            return fail(STGCN_ERR_UNSUPPORTED, "fused bf16 stem kernel does not cover C=%d V=%d K=%d T=%d", Cin, V, K, T);
+        if (terms == 3) return dispatch_stem<3>(x, P, W12, (const uint4 *)Wp, shift, y, N, Cin, T, V, K, sp, bf16out, st);
+        return dispatch_stem<1>(x, P, W12, (const uint4 *)Wp, shift, y, N, Cin, T, V, K, sp, bf16out, st);
+    }
     Bf16Plan pl;
     if (Tout < 1 || !plan_bf16(Cin, Cout, V, K, stride, Tout, terms, fused, pl))
         return fail(STGCN_ERR_UNSUPPORTED,
                     "bf16 MFMA kernel does not cover Cin=%d Cout=%d V=%d K=%d stride=%d T=%d (needs Cin%%16==0, "
                     "Cout%%128==0, tile rows that fit LDS)", Cin, Cout, V, K, stride, T);
     const uint4 *wp = (const uint4 *)Wp;
-    if (fused) {
-        if (terms == 3) return dispatch<3, true>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, st);
-        return dispatch<1, true>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, st);
-    }
-    if (terms == 3) return dispatch<3, false>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, st);
-    return dispatch<1, false>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, st);
+    if (terms == 3) return dispatch_tcn<3, false>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, st);
+    return dispatch_tcn<1, false>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, st);
 }
 
 }  // namespace stgcn

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STGCN_ABI_VERSION 1
+#define STGCN_ABI_VERSION 2
 
 typedef enum {
     STGCN_OK = 0,
@@ -117,7 +117,6 @@ int stgcn_tcn_forward(const float *x, const float *W, const float *scale, const 
  * The (N,C,T,V) activation between the two modules is produced tile by tile in LDS and never
  * written to HBM.  `prep` holds the folded graph-conv weights and the packed temporal weights:
  * fill it with stgcn_stem_prepare (stgcn_stem_prep_bytes bytes) once per weight update.
- * P_ws (N,S,V,V) is workspace and holds the attention matrices on return.
  */
 size_t stgcn_stem_prep_bytes(int Cin, int C, int K, int subsets, unsigned flags);
 /* 1 when the fused kernel covers the shape (else run stgcn_agcn_forward + stgcn_tcn_forward) */
@@ -126,17 +125,25 @@ int stgcn_stem_prepare(const float *Wd, const float *bd, const float *Wdown, con
                        const float *bn_scale, const float *bn_shift, const float *down_scale,
                        const float *down_shift, const float *Wt, const float *t_scale, void *prep,
                        int Cin, int C, int K, int subsets, unsigned flags, void *stream);
+/* Workspace of the fused stem (caller-provided, stgcn_stem_ws_bytes bytes): the attention matrices
+ * P (N,S,V,V) at offset 0 (valid on return) followed by per-pixel graph-conv features for the kernels
+ * that consume them. */
+size_t stgcn_stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int subsets, unsigned flags);
+/* The two halves of stgcn_stem_forward_prepared, separately launchable (e.g. to time them):
+ * stgcn_stem_attention fills the workspace; stgcn_stem_tail_prepared launches only the fused
+ * graph-conv + temporal-conv kernel on a filled workspace. */
+int stgcn_stem_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
+                         const float *Wb, const float *bb, void *ws, size_t ws_bytes, int N, int Cin,
+                         int C, int T, int V, int inter_c, int subsets, int K, unsigned flags,
+                         void *stream);
+int stgcn_stem_tail_prepared(const float *x, const void *ws, size_t ws_bytes, const void *prep,
+                             const float *t_shift, void *out, int N, int Cin, int C, int T, int V,
+                             int subsets, int K, unsigned flags, void *stream);
 int stgcn_stem_forward_prepared(const float *x, const float *A_eff, const float *Wa,
                                 const float *ba, const float *Wb, const float *bb,
-                                const void *prep, const float *t_shift, float *P_ws, void *out,
-                                int N, int Cin, int C, int T, int V, int inter_c, int subsets,
-                                int K, unsigned flags, void *stream);
-
-/* Second half of stgcn_stem_forward_prepared alone: P (N,S,V,V) already holds the attention matrices
- * (from stgcn_agcn_attention); launches only the fused graph-conv + temporal-conv kernel. */
-int stgcn_stem_tail_prepared(const float *x, const float *P, const void *prep, const float *t_shift,
-                             void *out, int N, int Cin, int C, int T, int V, int subsets, int K,
-                             unsigned flags, void *stream);
+                                const void *prep, const float *t_shift, void *ws, size_t ws_bytes,
+                                void *out, int N, int Cin, int C, int T, int V, int inter_c,
+                                int subsets, int K, unsigned flags, void *stream);
 
 #ifdef __cplusplus
 }

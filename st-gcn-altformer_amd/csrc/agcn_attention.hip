@@ -41,7 +41,11 @@ __device__ __forceinline__ void softmax_columns_store(float *Sm, const float *__
         }
         const float *Ae = A_eff + (size_t)(s0 + s) * V * V + w;
         float *Po = Pn + (size_t)s * V * V + w;
-        for (int v = 0; v < V; ++v) Po[v * V] = col[v * V] / sum + Ae[v * V];
+        for (int v = 0; v < V; ++v) {
+            const float pv = col[v * V] / sum + Ae[v * V];
+            col[v * V] = pv;  // keep the final P in LDS for the feature pass
+            Po[v * V] = pv;
+        }
     }
 }
 
@@ -49,7 +53,8 @@ template <int MAXIT>
 __global__ __launch_bounds__(256) void attention_folded_kernel(
     const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
     const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
-    float *__restrict__ P, int Cin, int T, int V, int inter_c, int S, int TC, int Rp) {
+    float *__restrict__ P, float *__restrict__ feat, int Cin, int T, int V, int inter_c, int S, int TC,
+    int Rp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
@@ -154,6 +159,45 @@ __global__ __launch_bounds__(256) void attention_folded_kernel(
     }
     __syncthreads();
     softmax_columns_store(Sm, A_eff, P + (size_t)n * S * V * V, S, V, 0, tid, 256);
+
+    // Optional feature pass for the fused stem (Cin = 3, S = 3 only): per pixel (t,w) the 12 graph-conv
+    // features [u_0, u_1, u_2, x] with u_s[k] = sum_v x[k,t,v] P_s[v,w]  (model/unit_agcn.py:87-88), then a
+    // constant 1 that multiplies the folded bias and 3 zeros -> feat[n][t*V+w][16], 64 B per pixel, coalesced.
+    if (feat == nullptr) return;
+    float *Xf = U;  // [3][tcf*V], reuses the dead Gram region
+    const int TCF = (R * R) / (3 * V);
+    float4 *fo = reinterpret_cast<float4 *>(feat) + (size_t)n * T * V * 4;
+    for (int t0 = 0; t0 < T; t0 += TCF) {
+        const int tcf = min(TCF, T - t0);
+        const int px = tcf * V;
+        __syncthreads();  // P complete in Sm / previous chunk consumed
+        for (int e = tid; e < 3 * px; e += 256) {
+            const int k = e / px, p = e - k * px;
+            Xf[e] = xn[((size_t)k * T + t0) * V + p];
+        }
+        __syncthreads();
+        for (int p = tid; p < px; p += 256) {
+            const int tt = p / V, w = p - tt * V;
+            float u[9];
+#pragma unroll
+            for (int f = 0; f < 9; ++f) u[f] = 0.f;
+            for (int v = 0; v < V; ++v) {
+                const float x0 = Xf[tt * V + v], x1 = Xf[px + tt * V + v], x2 = Xf[2 * px + tt * V + v];
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) {
+                    const float pw = Sm[(s3 * V + v) * V + w];
+                    u[s3 * 3 + 0] = fmaf(x0, pw, u[s3 * 3 + 0]);
+                    u[s3 * 3 + 1] = fmaf(x1, pw, u[s3 * 3 + 1]);
+                    u[s3 * 3 + 2] = fmaf(x2, pw, u[s3 * 3 + 2]);
+                }
+            }
+            float4 *dst = fo + ((size_t)t0 * V + p) * 4;
+            dst[0] = make_float4(u[0], u[1], u[2], u[3]);
+            dst[1] = make_float4(u[4], u[5], u[6], u[7]);
+            dst[2] = make_float4(u[8], Xf[p], Xf[px + p], Xf[2 * px + p]);
+            dst[3] = make_float4(1.f, 0.f, 0.f, 0.f);
+        }
+    }
 }
 
 // Generic Cin: one workgroup per (subset, clip).
@@ -227,9 +271,20 @@ __global__ __launch_bounds__(256) void attention_generic_kernel(
 
 }  // namespace
 
+// true when launch_attention can also emit the (N, T*V, 16) feature tensor (folded kernel, Cin = 3, S = 3)
+bool attention_emits_features(int Cin, int V, int S) {
+    if (Cin != 3 || S != 3) return false;
+    const int C1 = Cin + 1, R = Cin * V + 1;
+    const int ntiles = ceil_div(R, TM) * ceil_div(R, TN);
+    const size_t gs_floats = (size_t)R * R + (size_t)S * V * V;
+    return S * C1 * C1 <= MS_FLOATS && ntiles <= 8 * 256 && (MS_FLOATS + gs_floats) * 4 <= 150 * 1024;
+}
+
 int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
-                     const float *Wb, const float *bb, float *P, int N, int Cin, int T, int V,
+                     const float *Wb, const float *bb, float *P, float *feat, int N, int Cin, int T, int V,
                      int inter_c, int S, hipStream_t st) {
+    if (feat != nullptr && (Cin != 3 || S != 3))
+        return fail(STGCN_ERR_UNSUPPORTED, "attention: the feature pass covers Cin=3, 3 subsets (got %d, %d)", Cin, S);
     const int C1 = Cin + 1;
     const int R = Cin * V + 1;
     const int nTr = ceil_div(R, TM), nTc = ceil_div(R, TN);
@@ -254,7 +309,7 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
     do {                                                                                      \
         STGCN_HIP_CHECK(allow_lds(attention_folded_kernel<MI>, lds));                         \
         hipLaunchKernelGGL(attention_folded_kernel<MI>, dim3(N), dim3(256), lds, st, x, A_eff, \
-                           Wa, ba, Wb, bb, P, Cin, T, V, inter_c, S, TC, Rp);                 \
+                           Wa, ba, Wb, bb, P, feat, Cin, T, V, inter_c, S, TC, Rp);           \
     } while (0)
         if (maxit <= 1) LAUNCH_FOLDED(1);
         else if (maxit <= 2) LAUNCH_FOLDED(2);
@@ -265,6 +320,8 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
         return STGCN_OK;
     }
     // generic path
+    if (feat != nullptr)
+        return fail(STGCN_ERR_UNSUPPORTED, "attention: V=%d too large for the feature pass", V);
     const int maxit = ceil_div(V * V, 256);
     if (maxit > 16) return fail(STGCN_ERR_UNSUPPORTED, "attention: V=%d too large (max 64)", V);
     const size_t budget = (size_t)96 * 1024 / 4;

@@ -84,7 +84,8 @@ int stgcn_agcn_attention(const float *x, const float *A_eff, const float *Wa, co
     REQUIRE_PTR(P);
     REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(inter_c); REQUIRE_POS(subsets);
     if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "attention: N=%d > 65535 clips per call", N);
-    return launch_attention(x, A_eff, Wa, ba, Wb, bb, P, N, Cin, T, V, inter_c, subsets, (hipStream_t)stream);
+    return launch_attention(x, A_eff, Wa, ba, Wb, bb, P, nullptr, N, Cin, T, V, inter_c, subsets,
+                            (hipStream_t)stream);
 }
 
 int stgcn_agcn_forward(const float *x, const float *A_eff, const float *Wa, const float *ba,
@@ -166,24 +167,46 @@ int stgcn_stem_prepare(const float *Wd, const float *bd, const float *Wdown, con
                                prep, Cin, C, K, subsets, flags, (hipStream_t)stream);
 }
 
-int stgcn_stem_forward_prepared(const float *x, const float *A_eff, const float *Wa, const float *ba,
-                                const float *Wb, const float *bb, const void *prep, const float *t_shift,
-                                float *P_ws, void *out, int N, int Cin, int C, int T, int V, int inter_c,
-                                int subsets, int K, unsigned flags, void *stream) {
-    REQUIRE_PTR(prep); REQUIRE_PTR(t_shift); REQUIRE_PTR(out);
-    REQUIRE_POS(C); REQUIRE_POS(K);
-    int rc = stgcn_agcn_attention(x, A_eff, Wa, ba, Wb, bb, P_ws, N, Cin, T, V, inter_c, subsets, stream);
-    if (rc != STGCN_OK) return rc;
-    return launch_stem(x, P_ws, prep, t_shift, out, N, Cin, C, T, V, subsets, K, flags, (hipStream_t)stream);
+size_t stgcn_stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int subsets, unsigned flags) {
+    if (N <= 0 || Cin <= 0 || C <= 0 || T <= 0 || V <= 0 || K <= 0 || subsets <= 0) return 0;
+    return stem_ws_bytes(N, Cin, C, T, V, K, subsets, flags);
 }
 
-int stgcn_stem_tail_prepared(const float *x, const float *P, const void *prep, const float *t_shift, void *out,
-                             int N, int Cin, int C, int T, int V, int subsets, int K, unsigned flags,
+int stgcn_stem_attention(const float *x, const float *A_eff, const float *Wa, const float *ba, const float *Wb,
+                         const float *bb, void *ws, size_t ws_bytes, int N, int Cin, int C, int T, int V,
+                         int inter_c, int subsets, int K, unsigned flags, void *stream) {
+    REQUIRE_PTR(x); REQUIRE_PTR(A_eff); REQUIRE_PTR(Wa); REQUIRE_PTR(ba); REQUIRE_PTR(Wb); REQUIRE_PTR(bb);
+    REQUIRE_PTR(ws);
+    REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(C); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(inter_c);
+    REQUIRE_POS(subsets); REQUIRE_POS(K);
+    if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "stem: N=%d > 65535 clips per call", N);
+    const size_t need = stem_ws_bytes(N, Cin, C, T, V, K, subsets, flags);
+    if (ws_bytes < need) return fail(STGCN_ERR_WORKSPACE, "stem: workspace %zu B < %zu B", ws_bytes, need);
+    return launch_attention(x, A_eff, Wa, ba, Wb, bb, (float *)ws,
+                            stem_ws_features(ws, N, Cin, C, T, V, K, subsets, flags), N, Cin, T, V, inter_c, subsets,
+                            (hipStream_t)stream);
+}
+
+int stgcn_stem_tail_prepared(const float *x, const void *ws, size_t ws_bytes, const void *prep, const float *t_shift,
+                             void *out, int N, int Cin, int C, int T, int V, int subsets, int K, unsigned flags,
                              void *stream) {
-    REQUIRE_PTR(x); REQUIRE_PTR(P); REQUIRE_PTR(prep); REQUIRE_PTR(t_shift); REQUIRE_PTR(out);
+    REQUIRE_PTR(x); REQUIRE_PTR(ws); REQUIRE_PTR(prep); REQUIRE_PTR(t_shift); REQUIRE_PTR(out);
     REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(C); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(subsets);
     REQUIRE_POS(K);
-    return launch_stem(x, P, prep, t_shift, out, N, Cin, C, T, V, subsets, K, flags, (hipStream_t)stream);
+    const size_t need = stem_ws_bytes(N, Cin, C, T, V, K, subsets, flags);
+    if (ws_bytes < need) return fail(STGCN_ERR_WORKSPACE, "stem: workspace %zu B < %zu B", ws_bytes, need);
+    return launch_stem(x, (const float *)ws, stem_ws_features(const_cast<void *>(ws), N, Cin, C, T, V, K, subsets, flags),
+                       prep, t_shift, out, N, Cin, C, T, V, subsets, K, flags, (hipStream_t)stream);
+}
+
+int stgcn_stem_forward_prepared(const float *x, const float *A_eff, const float *Wa, const float *ba,
+                                const float *Wb, const float *bb, const void *prep, const float *t_shift, void *ws,
+                                size_t ws_bytes, void *out, int N, int Cin, int C, int T, int V, int inter_c,
+                                int subsets, int K, unsigned flags, void *stream) {
+    int rc = stgcn_stem_attention(x, A_eff, Wa, ba, Wb, bb, ws, ws_bytes, N, Cin, C, T, V, inter_c, subsets, K, flags,
+                                  stream);
+    if (rc != STGCN_OK) return rc;
+    return stgcn_stem_tail_prepared(x, ws, ws_bytes, prep, t_shift, out, N, Cin, C, T, V, subsets, K, flags, stream);
 }
 
 }  // extern "C"

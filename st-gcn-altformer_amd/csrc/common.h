@@ -59,8 +59,8 @@ int launch_bn_fold(const float *w, const float *b, const float *rm, const float 
                    const float *cb, float eps, float *scale, float *shift, int C, hipStream_t st);
 
 int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
-                     const float *Wb, const float *bb, float *P, int N, int Cin, int T, int V,
-                     int inter_c, int S, hipStream_t st);
+                     const float *Wb, const float *bb, float *P, float *feat, int N, int Cin, int T,
+                     int V, int inter_c, int S, hipStream_t st);
 
 int launch_agcn_expand(const float *x, const float *P, const float *Wd, const float *bd,
                        const float *Wdown, const float *bdown, const float *bn_scale,
@@ -85,13 +85,21 @@ int launch_tcn_bf16(const float *x, const float *P, const float *W12, const void
 bool tcn_mfma_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
 bool stem_fused_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags);
 
+// large-tile persistent bf16 stem (stem_bf16_v4.hip); consumes the feature tensor the attention kernel emits
+bool attention_emits_features(int Cin, int V, int S);
+bool stem_v4_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags);
+int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, const float *shift, void *out, int N,
+                   int C, int T, int V, int K, unsigned flags, hipStream_t st);
+
 // fused stem
 size_t stem_prep_bytes(int Cin, int C, int K, int S, unsigned flags);
 int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, const float *bdown,
                         const float *bn_scale, const float *bn_shift, const float *down_scale,
                         const float *down_shift, const float *Wt, const float *t_scale, void *prep,
                         int Cin, int C, int K, int S, unsigned flags, hipStream_t st);
-int launch_stem(const float *x, const float *P, const void *prep, const float *t_shift, void *out,
-                int N, int Cin, int C, int T, int V, int S, int K, unsigned flags, hipStream_t st);
+size_t stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int S, unsigned flags);
+float *stem_ws_features(void *ws, int N, int Cin, int C, int T, int V, int K, int S, unsigned flags);  // NULL if unused
+int launch_stem(const float *x, const float *P, const float *feat, const void *prep, const float *t_shift,
+                void *out, int N, int Cin, int C, int T, int V, int S, int K, unsigned flags, hipStream_t st);
 
 }  // namespace stgcn

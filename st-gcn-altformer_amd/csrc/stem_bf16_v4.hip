@@ -1,0 +1,295 @@
+// KF4 — fused stem on the bf16 matrix cores, large-tile persistent form (STGCN_MATH_BF16X3 / _BF16, K = 9).
+//
+// Differences from the 128-pixel kernels in tcn_bf16.hip, each aimed at a measured loss of those:
+//   * tile = 128 channels x 256 pixels, 512 threads = 8 waves as 2 (channel halves) x 4 (pixel quarters), one
+//     workgroup per CU: the halo (8V pixels) costs 1.8x instead of 2.6x producer work and the weight
+//     fragments are shared by 4 waves.
+//   * weights reach the waves through an LDS ring filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+//     wave-instruction = exactly one packed MFMA fragment, lane-linear): 8 fragments per tap, one per
+//     wave, staged 3 taps (one "stage") ahead into the other half of a 2-stage ring; a stage ends with
+//     vmcnt(0) + barrier.  No weight traffic through VGPRs/L1 (it saturated the vector L1 before).
+//   * the 12 graph-conv features per pixel are NOT recomputed per tile: the attention kernel emits them
+//     once per clip (feat[n][pixel][16], 64 B per pixel) and the tile's rows are DMA'd into the feature
+//     tile Fs; rows outside the clip are zeroed (the temporal conv's zero padding).
+//   * persistent: grid = one workgroup per CU looping over tiles; the next tile's feature rows are DMA'd
+//     during the last channel chunk of the current tile (Fs is idle then), so a tile's serial part is
+//     only its epilogue stores + the production of channel chunk 0.
+//
+// Everything else (LDS image layout, k-step = 16 channels of one tap, 2x2 MFMA blocks per wave, MFMA
+// producer relu(W12 . Fs^T) via v_mfma_f32_16x16x4_f32, hi/lo split) is as described in tcn_bf16.hip.
+#include "bf16_common.h"
+
+namespace stgcn {
+
+namespace {
+
+using namespace bf16k;
+
+constexpr int NP4 = 256;   // output pixels per tile
+constexpr int NT4 = 512;   // threads per workgroup
+constexpr int KT4 = 9;     // temporal taps (the only kernel size this kernel is built for)
+constexpr int STG = 3;     // taps per weight stage
+constexpr int FRAG = 1024; // bytes of one packed MFMA weight fragment (64 lanes x 16 B)
+constexpr int STAGE_BYTES = STG * 8 * FRAG;
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__device__ __forceinline__ void dma16(const void *g, void *l) {  // 64 lanes x 16 B -> LDS at l + lane*16
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+template <int PB, int TERMS, bool BF16OUT>
+__global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
+    const float4 *__restrict__ feat, const float *__restrict__ W12, const uint4 *__restrict__ Wp,
+    const float *__restrict__ shift, void *y, int C, int T, int V, int ROWS, int tiles_per_clip, int ntiles,
+    int abl) {
+    extern __shared__ __attribute__((aligned(16))) char smem4[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int TV = T * V;
+    const int nch = C / CCB;                 // channel chunks (C = 128 -> 8)
+    const int nstage = nch * (KT4 / STG);    // weight stages per tile
+    const int img_bytes = ROWS * PXB;
+    const int buf_bytes = img_bytes * (TERMS == 3 ? 2 : 1);
+    // LDS carve
+    float *W12s = reinterpret_cast<float *>(smem4);                 // [C][16]: folded graph conv, all C produced channels
+    char *ring = smem4 + C * W12P * 4;                              // 2 stages x 3 taps x 8 fragments
+    char *buf0 = ring + 2 * STAGE_BYTES;
+    char *buf1 = buf0 + buf_bytes;
+    float4 *Fs = reinterpret_cast<float4 *>(buf1 + buf_bytes);      // 4 planes of [ROWS] float4
+
+    const int cg = blockIdx.y;               // 128-channel group of the output
+    // weight fragment this wave DMAs each tap: f = wave -> m-block (f>>1), image (f&1)
+    const uint4 *wsrc = Wp + ((size_t)(cg * 4 + (wave >> 1)) * nch * KT4 * 2 + (wave & 1)) * 64 + lane;
+    auto dma_stage = [&](int gs) {           // stage gs (taps 3gs..3gs+2 of the flat k index) -> ring slot gs&1
+        char *dst = ring + (gs & 1) * STAGE_BYTES + wave * FRAG;
+        const int gsm = gs % nstage;         // weights repeat for every tile
+#pragma unroll
+        for (int t = 0; t < STG; ++t) dma16(wsrc + (size_t)(gsm * STG + t) * 128, dst + t * 8 * FRAG);
+    };
+    // feature rows of tile `tile` -> Fs (rows whose pixel lies outside the clip are fixed up afterwards)
+    auto dma_features = [&](int tile) {
+        const int n = tile / tiles_per_clip;
+        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NP4);
+        const float4 *src = feat + (size_t)n * TV * 4;
+        for (int c = wave * 64; c < 4 * ROWS; c += 8 * 64) {       // chunk c = plane q, rows j0 .. j0+63
+            const int q = c / ROWS, j = c - q * ROWS + lane;       // ROWS % 64 == 0
+            int gi = g.origin + j;
+            gi = max(0, min(gi, TV - 1));
+            dma16(src + (size_t)gi * 4 + q, reinterpret_cast<char *>(Fs + (size_t)q * ROWS + (c - q * ROWS)));
+        }
+    };
+    auto zero_invalid_rows = [&](int tile) {
+        const int n = tile / tiles_per_clip;
+        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NP4);
+        for (int j = tid; j < ROWS; j += NT4) {
+            const int gi = g.origin + j;
+            if (j >= g.span || gi < 0 || gi >= TV) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Fs[(size_t)q * ROWS + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    // ---- producer: one 16-pixel block of chunk `ch` -> hi/lo images of `buf` -------------------
+    const int pl = lane & 15, pg = lane >> 4;
+    auto produce_block = [&](char *buf, int ch, int bi) {
+        const int p = bi * 16 + pl;
+        const float4 wa = *reinterpret_cast<const float4 *>(W12s + (ch * CCB + pl) * W12P + 4 * pg);
+        const float4 fb = Fs[(size_t)pg * ROWS + p];
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, fb.x, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, fb.y, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, fb.z, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, fb.w, d, 0, 0, 0);
+        const float v0 = fmaxf(d[0], 0.f), v1 = fmaxf(d[1], 0.f), v2 = fmaxf(d[2], 0.f), v3 = fmaxf(d[3], 0.f);
+        const unsigned h0 = pack_bf16x2(v0, v1), h1 = pack_bf16x2(v2, v3);
+        const int off = lds_off(p, pg >> 1) + (pg & 1) * 8;
+        *reinterpret_cast<uint2 *>(buf + off) = make_uint2(h0, h1);
+        if constexpr (TERMS == 3) {
+            const unsigned l0 = pack_bf16x2(v0 - bf16_lo_to_f32(h0), v1 - bf16_hi_to_f32(h0));
+            const unsigned l1 = pack_bf16x2(v2 - bf16_lo_to_f32(h1), v3 - bf16_hi_to_f32(h1));
+            *reinterpret_cast<uint2 *>(buf + img_bytes + off) = make_uint2(l0, l1);
+        }
+    };
+
+    // ---- one-time setup ----------------------------------------------------------------------
+    for (int e = tid; e < C * W12P; e += NT4) W12s[e] = W12[e];
+    int tile = blockIdx.x;
+    if (tile < ntiles) dma_features(tile);
+    dma_stage(0);
+    __syncthreads();                          // W12s, Fs(tile), weight stage 0 landed
+    if (tile < ntiles) zero_invalid_rows(tile);
+    __syncthreads();
+
+    int gs = 0;                               // running weight-stage counter (ring slot = gs & 1)
+    const int h = lane >> 5;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_clip;
+        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NP4);
+        const int nblk = (g.span + 15) >> 4;
+        const int next_tile = tile + gridDim.x;
+
+        // chunk 0 of this tile
+        for (int b = wave; b < nblk; b += 8) produce_block(buf0, 0, b);
+
+        int prow[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
+            q = min(q, g.q_last);
+            const int t = q / V, v = q - t * V;
+            prow[j] = (t - g.t_first) * V + v;
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+        __syncthreads();                      // chunk 0 visible
+
+        for (int ch = 0; ch < nch; ++ch) {
+            const char *cur = (ch & 1) ? buf1 : buf0;
+            char *nxt = (ch & 1) ? buf0 : buf1;
+            const bool last = ch + 1 == nch;
+            if (last && next_tile < ntiles) dma_features(next_tile);   // Fs is idle during the last chunk
+#pragma unroll
+            for (int st = 0; st < KT4 / STG; ++st, ++gs) {
+                dma_stage(gs + 1);            // next stage -> other ring slot (its readers passed the last barrier)
+                const char *aslot = ring + (gs & 1) * STAGE_BYTES + (wm * 4) * FRAG + lane * 16;
+#pragma unroll
+                for (int tt = 0; tt < STG; ++tt) {
+                    const int tap = st * STG + tt;
+                    Frag2<TERMS> a, b;
+                    if (!STGCN_ABL(16)) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            a.hi[m] = *reinterpret_cast<const uint4 *>(aslot + (tt * 8 + m * 2) * FRAG);
+                            if constexpr (TERMS == 3)
+                                a.lo[m] = *reinterpret_cast<const uint4 *>(aslot + (tt * 8 + m * 2 + 1) * FRAG);
+                        }
+                    }
+                    if (!STGCN_ABL(8)) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int off = lds_off(prow[j] + tap * V, h);
+                            b.hi[j] = *reinterpret_cast<const uint4 *>(cur + off);
+                            if constexpr (TERMS == 3) b.lo[j] = *reinterpret_cast<const uint4 *>(cur + img_bytes + off);
+                        }
+                    }
+                    if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a, b);
+                    if (tap < PB && !STGCN_ABL(1))  // (last chunk: recomputes chunk nch-1 into the idle buffer; discarded)
+                        produce_block(nxt, min(ch + 1, nch - 1), min(wave + 8 * tap, nblk - 1));
+                }
+                __syncthreads();              // stage done: next weights landed (vmcnt 0) and visible; chunk boundary at st==2
+            }
+        }
+
+        // epilogue: D[row = channel][col = pixel], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        if (!STGCN_ABL(4)) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = cg * 128 + (wm * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float sh = shift[o];
+                    const size_t base = ((size_t)n * C + o) * TV;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
+                        if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[m][j][r] + sh, 0.f));
+                    }
+                }
+            }
+        }
+        if (next_tile < ntiles) {             // its feature rows landed at the last stage barrier
+            zero_invalid_rows(next_tile);
+            __syncthreads();
+        }
+    }
+}
+
+struct V4Plan {
+    int pb = 0, rows = 0, tiles_per_clip = 0;
+    size_t lds = 0;
+};
+
+inline bool plan_v4(int C, int T, int V, int K, int terms, V4Plan &pl) {
+    if (K != KT4 || C % 128 != 0) return false;
+    int dt = ceil_div(NP4 - 1, V);
+    if (dt > T - 1) dt = T - 1;
+    const int span = (dt + K) * V;
+    const int rows = (span + 63) / 64 * 64;          // feature DMA moves 64 rows per wave-instruction
+    const int pb = ceil_div(ceil_div(span, 16), 8);  // producer blocks per wave per chunk
+    if (pb > KT4) return false;
+    const size_t buf = (size_t)rows * PXB * (terms == 3 ? 2 : 1);
+    const size_t lds = (size_t)C * W12P * 4 + 2 * STAGE_BYTES + 2 * buf + (size_t)rows * 64;
+    if (lds > (size_t)kLdsBytes) return false;
+    pl.pb = pb;
+    pl.rows = rows;
+    pl.tiles_per_clip = ceil_div(T * V, NP4);
+    pl.lds = lds;
+    return true;
+}
+
+template <int PB, int TERMS>
+int launch_v4(const float4 *feat, const float *W12, const uint4 *Wp, const float *shift, void *y, int N, int C, int T,
+              int V, const V4Plan &pl, bool bf16out, int num_cu, hipStream_t st) {
+    const int ntiles = N * pl.tiles_per_clip;
+    const int gx = ntiles < num_cu ? ntiles : num_cu;
+    const dim3 grid(gx, C / 128, 1);
+    if (bf16out) {
+        auto kern = stem_bf16_v4_kernel<PB, TERMS, true>;
+        STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
+        hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
+                           pl.tiles_per_clip, ntiles, ablate_mask());
+    } else {
+        auto kern = stem_bf16_v4_kernel<PB, TERMS, false>;
+        STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
+        hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
+                           pl.tiles_per_clip, ntiles, ablate_mask());
+    }
+    STGCN_LAUNCH_CHECK("stem_bf16_v4_kernel");
+    return STGCN_OK;
+}
+
+}  // namespace
+
+bool stem_v4_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags) {
+    const unsigned math = flags & STGCN_MATH_MASK;
+    if (math != STGCN_MATH_BF16X3 && math != STGCN_MATH_BF16) return false;
+    if (Cin != 3 || S != 3 || T < 1) return false;
+    V4Plan pl;
+    return plan_v4(C, T, V, K, math == STGCN_MATH_BF16X3 ? 3 : 1, pl) && attention_emits_features(Cin, V, S);
+}
+
+int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, const float *shift, void *out, int N,
+                   int C, int T, int V, int K, unsigned flags, hipStream_t st) {
+    const unsigned math = flags & STGCN_MATH_MASK;
+    const int terms = math == STGCN_MATH_BF16X3 ? 3 : 1;
+    const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
+    V4Plan pl;
+    if (!plan_v4(C, T, V, K, terms, pl))
+        return fail(STGCN_ERR_UNSUPPORTED, "stem v4 kernel does not cover C=%d T=%d V=%d K=%d", C, T, V, K);
+    int dev = 0, num_cu = 256;
+    STGCN_HIP_CHECK(hipGetDevice(&dev));
+    STGCN_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const float4 *f4 = (const float4 *)feat;
+    const float *W12 = (const float *)prep_w12;
+    const uint4 *wp = (const uint4 *)Wp;
+#define GO(PB)                                                                                                  \
+    return terms == 3 ? launch_v4<PB, 3>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, num_cu, st)          \
+                      : launch_v4<PB, 1>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, num_cu, st)
+    if (pl.pb <= 4) GO(4);
+    if (pl.pb <= 6) GO(6);
+    GO(9);
+#undef GO
+}
+
+}  // namespace stgcn

@@ -26,55 +26,16 @@
 //                 Fused stem: relu(W12 . feat + b) from the 12 graph-conv features each thread keeps in
 //                 registers for its 1-3 tile pixels (W12 is wave-uniform: scalar loads).
 //                 Stand-alone temporal conv: fp32 activations loaded from HBM/L2, coalesced along pixels.
-#include "common.h"
+#include "bf16_common.h"
 
 namespace stgcn {
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-
-#ifdef STGCN_ABLATION  // diagnostic builds only: 1 = producer, 2 = MFMAs, 4 = epilogue, 8 = B reads, 16 = A loads
-#define STGCN_ABL(bit) ((abl & (bit)) != 0)
-#else
-#define STGCN_ABL(bit) false
-#endif
+using namespace bf16k;
 
 constexpr int NPB = 128;  // output pixels per workgroup
 constexpr int NT = 256;   // threads per workgroup
-constexpr int CCB = 16;   // input channels per LDS chunk = one 16-deep k-step per tap
-constexpr int PXB = 32;   // bytes per pixel row of one image
-constexpr int W12P = 16;  // row of the folded graph-conv matrix: 12 weights, bias, pad
-
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {  // RNE; a in the low half
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo_to_f32(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf16_hi_to_f32(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
-
-// 8 fp32 -> 8 bf16 "hi" and 8 bf16 "lo" residuals
-__device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo) {
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-        l[i] = pack_bf16x2(v[2 * i] - bf16_lo_to_f32(h[i]), v[2 * i + 1] - bf16_hi_to_f32(h[i]));
-    }
-    hi = make_uint4(h[0], h[1], h[2], h[3]);
-    lo = make_uint4(l[0], l[1], l[2], l[3]);
-}
-
-__device__ __forceinline__ int lds_off(int p, int h) { return p * PXB + ((h ^ ((p >> 3) & 1)) << 4); }
-
-template <bool BF16OUT>
-__device__ __forceinline__ void store_out(void *y, size_t idx, float v) {
-    if constexpr (BF16OUT) reinterpret_cast<unsigned short *>(y)[idx] = (unsigned short)(pack_bf16x2(v, 0.f) & 0xffffu);
-    else reinterpret_cast<float *>(y)[idx] = v;
-}
 
 // weight packing: Wp (bf16) index (((((mb*nch+ch)*K+tap)*2+img)*64+lane)*8+j
 //   o = mb*32 + (lane&31), c = ch*16 + 8*(lane>>5) + j, value = split(scale[o]*W[o][c][tap])[img]
@@ -98,47 +59,6 @@ __global__ void tcn_pack_bf16_kernel(const float *__restrict__ W, const float *_
     const unsigned h = pack_bf16x2(w, 0.f) & 0xffffu;
     const unsigned l = pack_bf16x2(w - bf16_lo_to_f32(h), 0.f) & 0xffffu;
     Wp[e] = (unsigned short)(img ? l : h);
-}
-
-struct TileGeomB {
-    int q0, q_last, t_first, span, origin;
-};
-
-__device__ __forceinline__ TileGeomB tile_geom_b(int tile, int V, int K, int stride, int Tout) {
-    TileGeomB g;
-    g.q0 = tile * NPB;
-    g.q_last = min(g.q0 + NPB, Tout * V) - 1;
-    g.t_first = g.q0 / V;
-    const int t_last = g.q_last / V;
-    g.span = ((t_last - g.t_first) * stride + K) * V;
-    g.origin = (g.t_first * stride - (K - 1) / 2) * V;
-    return g;
-}
-
-template <int TERMS>
-struct Frag2 {  // operands of one k-step for 2 MFMA blocks: [block] hi (+ lo)
-    uint4 hi[2];
-    uint4 lo[TERMS == 3 ? 2 : 1];
-};
-
-// 12 (or 4) MFMAs of one k-step: 2 channel blocks x 2 pixel blocks
-template <int TERMS>
-__device__ __forceinline__ void mfma_kstep_bf16(f32x16 (&acc)[2][2], const Frag2<TERMS> &a, const Frag2<TERMS> &b) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, a.hi[m]);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi[n]);
-            if constexpr (TERMS == 3) {
-                const bf16x8 al = __builtin_bit_cast(bf16x8, a.lo[m]);
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, b.lo[n]);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m][n], 0, 0, 0);
-            }
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m][n], 0, 0, 0);
-        }
-    }
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -432,8 +352,15 @@ __global__ __launch_bounds__(NT) void stem_mfma_bf16_kernel(
     const int buf_bytes = img_bytes * (TERMS == 3 ? 2 : 1);
     char *buf0 = smem_b;
     char *buf1 = smem_b + buf_bytes;
-    float *Fs = reinterpret_cast<float *>(smem_b + 2 * buf_bytes);  // [ROWS][16]
+    float *Fs = reinterpret_cast<float *>(smem_b + 2 * buf_bytes);  // 4 planes of [ROWS] float4
     const int nblk = (g.span + 15) >> 4;                            // 16-pixel producer blocks of this tile
+#ifdef STGCN_ABLATION
+    if (STGCN_ABL(32)) {  // experiment: de-phase the second workgroup slot of every CU by ~half a tile
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin >= 256 && lin < 512)
+            for (int i = 0; i < (abl >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     // ---- prologue: stage P and the skeleton tile, build the feature tile ---------------------
     {
@@ -473,9 +400,10 @@ __global__ __launch_bounds__(NT) void stem_mfma_bf16_kernel(
                 for (int k = 0; k < CIN0; ++k) feat[S * CIN0 + k] = Xs[k * g.span + j];
                 feat[F] = 1.f;  // multiplies the folded bias; 0 outside the clip
             }
-            float4 *dst = reinterpret_cast<float4 *>(Fs + (size_t)j * 16);
+            float4 *dst = reinterpret_cast<float4 *>(Fs) + j;  // plane q holds features 4q..4q+3 of every pixel
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = make_float4(feat[4 * q], feat[4 * q + 1], feat[4 * q + 2], feat[4 * q + 3]);
+            for (int q = 0; q < 4; ++q)
+                dst[(size_t)q * ROWS] = make_float4(feat[4 * q], feat[4 * q + 1], feat[4 * q + 2], feat[4 * q + 3]);
         }
         __syncthreads();  // Fs complete; Ps/Xs dead -> buf0/buf1 may be overwritten
     }
@@ -488,7 +416,7 @@ __global__ __launch_bounds__(NT) void stem_mfma_bf16_kernel(
     };
     auto produce_block = [&](char *buf, const float4 &wa, int bi) {
         const int p = bi * 16 + pl;
-        const float4 fb = *reinterpret_cast<const float4 *>(Fs + (size_t)p * 16 + 4 * pg);
+        const float4 fb = reinterpret_cast<const float4 *>(Fs)[(size_t)pg * ROWS + p];  // conflict-free: slot = p mod 16
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
         d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, fb.x, d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, fb.y, d, 0, 0, 0);
@@ -552,9 +480,11 @@ __global__ __launch_bounds__(NT) void stem_mfma_bf16_kernel(
         }
     };
 
-    Frag2<TERMS> a0 = {}, a1 = {}, a2 = {};
+    Frag2<TERMS> a0 = {}, a1 = {}, a2 = {}, a3 = {}, a4 = {};  // weight fragments of taps kidx .. kidx+4
     load_a(a0, 0);
     load_a(a1, 1);
+    load_a(a2, 2);
+    load_a(a3, 3);
     int kidx = 0;
     for (int ch = 0; ch < nch; ++ch) {
         const char *cur = (ch & 1) ? buf1 : buf0;
@@ -566,12 +496,14 @@ __global__ __launch_bounds__(NT) void stem_mfma_bf16_kernel(
         if constexpr (KT == 9) {
 #define STGCN_TAP(TAP)                                                                                  \
     do {                                                                                                \
-        load_a(a2, kidx + 2);                                                                           \
+        load_a(a4, kidx + 4);                                                                           \
         load_b(b1, cur, (TAP) + 1 < 9 ? (TAP) + 1 : (TAP));                                             \
         if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a0, b0);                                         \
         if ((TAP) < PB && !STGCN_ABL(1)) produce_block(nxt, wcur, min(wave + 4 * (TAP), nblk - 1));     \
         a0 = a1;                                                                                        \
         a1 = a2;                                                                                        \
+        a2 = a3;                                                                                        \
+        a3 = a4;                                                                                        \
         b0 = b1;                                                                                        \
         ++kidx;                                                                                         \
     } while (0)
@@ -587,11 +519,13 @@ __global__ __launch_bounds__(NT) void stem_mfma_bf16_kernel(
 #undef STGCN_TAP
         } else {
             for (int k = 0; k < K; ++k, ++kidx) {
-                load_a(a2, kidx + 2);
+                load_a(a4, kidx + 4);
                 load_b(b1, cur, k + 1 < K ? k + 1 : k);
                 if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a0, b0);
                 a0 = a1;
                 a1 = a2;
+                a2 = a3;
+                a3 = a4;
                 b0 = b1;
             }
             if (ch + 1 < nch)

@@ -572,6 +572,7 @@ static bool stem_shape_ok(int Cin, int C, int V, int K, int S, int T) {
 bool stem_fused_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags) {
     const unsigned math = flags & STGCN_MATH_MASK;
     if (Cin != 3 || S != 3 || T < 1) return false;
+    if (stem_v4_supported(Cin, C, T, V, K, S, flags)) return true;
     if (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) return bf16_supported(C, C, T, V, K, 1, flags, true);
     return math == STGCN_MATH_F32 && stem_shape_ok(Cin, C, V, K, S, T);
 }
@@ -592,11 +593,28 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
     return launch_tcn_pack(Wt, t_scale, (char *)prep + stem_w12_bytes(C), C, C, K, flags, st);
 }
 
-int launch_stem(const float *x, const float *P, const void *prep, const float *t_shift, void *out, int N,
-                int Cin, int C, int T, int V, int S, int K, unsigned flags, hipStream_t st) {
+// workspace of the fused stem: [ P : N*S*V*V floats, 256-B aligned ][ features : N*T*V*16 floats, when used ]
+static size_t stem_ws_p_bytes(int N, int V, int S) { return align_up((size_t)N * S * V * V * sizeof(float), 256); }
+
+size_t stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {
+    size_t b = stem_ws_p_bytes(N, V, S);
+    if (stem_v4_supported(Cin, C, T, V, K, S, flags)) b += (size_t)N * T * V * 16 * sizeof(float);
+    return b;
+}
+
+float *stem_ws_features(void *ws, int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {
+    if (!stem_v4_supported(Cin, C, T, V, K, S, flags)) return nullptr;
+    return reinterpret_cast<float *>(static_cast<char *>(ws) + stem_ws_p_bytes(N, V, S));
+}
+
+int launch_stem(const float *x, const float *P, const float *feat, const void *prep, const float *t_shift,
+                void *out, int N, int Cin, int C, int T, int V, int S, int K, unsigned flags, hipStream_t st) {
     const unsigned math = flags & STGCN_MATH_MASK;
     const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
     if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "stem: N=%d > 65535 clips per call", N);
+    if (feat != nullptr && stem_v4_supported(Cin, C, T, V, K, S, flags))
+        return launch_stem_v4(feat, prep, (const char *)prep + stem_w12_bytes(C), t_shift, out, N, C, T, V, K, flags,
+                              st);
     if (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) {
         if (Cin != 3 || S != 3)
             return fail(STGCN_ERR_UNSUPPORTED, "stem: fused kernel covers Cin=3, 3 subsets (got %d, %d)", Cin, S);

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STGCN_LIB") or os.path.join(_HERE, "libstgcn_hip.so")   # STGCN_LIB: diagnostic builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # stgcn_math / flags (include/stgcn_hip.h)
 MATH_F32 = 0
@@ -41,8 +41,10 @@ PROTOTYPES = {
     "stgcn_stem_prep_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_uint]),
     "stgcn_stem_supported": (c_int, [c_int] * 6 + [c_uint]),
     "stgcn_stem_prepare": (c_int, [_P] * 11 + [c_int] * 4 + [c_uint, _P]),
-    "stgcn_stem_forward_prepared": (c_int, [_P] * 10 + [c_int] * 8 + [c_uint, _P]),
-    "stgcn_stem_tail_prepared": (c_int, [_P] * 5 + [c_int] * 7 + [c_uint, _P]),
+    "stgcn_stem_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
+    "stgcn_stem_attention": (c_int, [_P] * 7 + [c_size_t] + [c_int] * 8 + [c_uint, _P]),
+    "stgcn_stem_tail_prepared": (c_int, [_P] * 2 + [c_size_t] + [_P] * 3 + [c_int] * 7 + [c_uint, _P]),
+    "stgcn_stem_forward_prepared": (c_int, [_P] * 9 + [c_size_t] + [_P] + [c_int] * 8 + [c_uint, _P]),
 }
 
 _lib = None

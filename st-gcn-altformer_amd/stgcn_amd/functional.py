@@ -172,8 +172,8 @@ def stem_prepare(Wd, bd, Wdown, bdown, bn_scale, bn_shift, down_scale, down_shif
 
 
 def stem_forward(x, A_eff, Wa, ba, Wb, bb, prep, t_shift, C, K, math=MATH_F32, out_bf16=False,
-                 out: Optional[torch.Tensor] = None, P_ws: Optional[torch.Tensor] = None):
-    """Fused tcn0(gcn0(x)).  Returns (out (N,C,T,V), P (N,S,V,V))."""
+                 out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
+    """Fused tcn0(gcn0(x)).  Returns (out (N,C,T,V), P (N,S,V,V) — a view of the workspace)."""
     dev = x.device
     N, Cin, T, V = x.shape
     S, inter_c, _ = Wa.shape
@@ -182,24 +182,26 @@ def stem_forward(x, A_eff, Wa, ba, Wb, bb, prep, t_shift, C, K, math=MATH_F32, o
         out = torch.empty(N, C, T, V, device=dev, dtype=odt)
     elif out.shape != (N, C, T, V) or out.dtype != odt or not out.is_contiguous() or out.device != dev:
         raise ValueError("stem_forward: `out` has the wrong shape/dtype/device")
-    if P_ws is None:
-        P_ws = torch.empty(N, S, V, V, device=dev, dtype=torch.float32)
+    fl = _flags(math, out_bf16)
+    need = _capi.lib().stgcn_stem_ws_bytes(N, Cin, C, T, V, K, S, fl)
+    if ws is None or ws.numel() * ws.element_size() < need or ws.device != dev:
+        ws = torch.empty((need + 3) // 4, device=dev, dtype=torch.float32)
+    ws_bytes = c_size_t(ws.numel() * ws.element_size())
     st = _stream(dev)
     with torch.cuda.device(dev):
-        _capi.call("stgcn_agcn_attention", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev),
+        _capi.call("stgcn_stem_attention", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev),
                    _dev_ptr(Wa, "Wa", dev), _dev_ptr(ba, "ba", dev), _dev_ptr(Wb, "Wb", dev),
-                   _dev_ptr(bb, "bb", dev), _dev_ptr(P_ws, "P_ws", dev), c_int(N), c_int(Cin), c_int(T),
-                   c_int(V), c_int(inter_c), c_int(S), st)
+                   _dev_ptr(bb, "bb", dev), _dev_ptr(ws, "ws", dev), ws_bytes, c_int(N), c_int(Cin), c_int(C),
+                   c_int(T), c_int(V), c_int(inter_c), c_int(S), c_int(K), c_uint(fl), st)
         timer = kernel_timer
         if timer is not None:
             timer.start("stem_tail", dev)
-        _capi.call("stgcn_stem_tail_prepared", _dev_ptr(x, "x", dev), _dev_ptr(P_ws, "P_ws", dev),
+        _capi.call("stgcn_stem_tail_prepared", _dev_ptr(x, "x", dev), _dev_ptr(ws, "ws", dev), ws_bytes,
                    c_void_p(prep.data_ptr()), _dev_ptr(t_shift, "t_shift", dev), c_void_p(out.data_ptr()),
-                   c_int(N), c_int(Cin), c_int(C), c_int(T), c_int(V), c_int(S), c_int(K),
-                   c_uint(_flags(math, out_bf16)), st)
+                   c_int(N), c_int(Cin), c_int(C), c_int(T), c_int(V), c_int(S), c_int(K), c_uint(fl), st)
         if timer is not None:
             timer.stop("stem_tail", dev)
-    return out, P_ws
+    return out, ws[:N * S * V * V].view(N, S, V, V)
 
 
 class KernelTimer:

@@ -275,6 +275,13 @@ def test_errors_are_loud(dev):
                        torch.zeros(3, 32, 5, device=dev), torch.zeros(3, 32, device=dev),
                        torch.zeros(3, 32, 5, device=dev), torch.zeros(3, 32, device=dev),
                        torch.zeros(1 << 20, device=dev, dtype=torch.uint8), torch.zeros(128, device=dev), 128, 9)
+    with pytest.raises(StgcnError) as e:             # workspace too small is reported, not overrun
+        from ctypes import c_int, c_size_t, c_uint, c_void_p
+        from stgcn_amd import _capi
+        z = torch.zeros(64, device=dev)
+        _capi.call("stgcn_stem_attention", *[c_void_p(z.data_ptr())] * 7, c_size_t(16), c_int(4), c_int(3), c_int(128),
+                   c_int(20), c_int(22), c_int(32), c_int(3), c_int(9), c_uint(0), c_void_p(0))
+    assert e.value.code == -3
 
 
 def test_stem_forward_prepared_entry_point(dev):
@@ -290,9 +297,14 @@ def test_stem_forward_prepared_entry_point(dev):
         ref = tcn(gcn(x))
     st, ts = gcn._staged(dev), tcn._staged(dev)
     out = torch.empty_like(ref)
-    P = torch.empty(x.shape[0], 3, 22, 22, device=dev)
+    from ctypes import c_size_t
+    lib = _capi.lib()
+    nbytes = lib.stgcn_stem_ws_bytes(x.shape[0], 3, 128, 180, 22, 9, 3, 0)
+    ws = torch.empty(nbytes // 4 + 1, device=dev)
     p = lambda t: c_void_p(t.data_ptr())
     _capi.call("stgcn_stem_forward_prepared", p(x), p(st["A_eff"]), p(st["Wa"]), p(st["ba"]), p(st["Wb"]), p(st["bb"]),
-               p(st["stem_prep"]), p(ts["shift"]), p(P), p(out), c_int(x.shape[0]), c_int(3), c_int(128), c_int(180),
-               c_int(22), c_int(32), c_int(3), c_int(9), c_uint(0), c_void_p(torch.cuda.current_stream().cuda_stream))
+               p(st["stem_prep"]), p(ts["shift"]), p(ws), c_size_t(ws.numel() * 4), p(out), c_int(x.shape[0]), c_int(3),
+               c_int(128), c_int(180), c_int(22), c_int(32), c_int(3), c_int(9), c_uint(0),
+               c_void_p(torch.cuda.current_stream().cuda_stream))
+    parity_gate(ws[:x.shape[0] * 3 * 22 * 22].view(-1, 3, 22, 22), gcn.last_attention, 1e-6, "P in workspace")
     assert torch.equal(out, ref)

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--frames", type=int, default=180)
     ap.add_argument("--graph", default="SHRE")
     ap.add_argument("--maths", default="f32,bf16x3,bf16")
-    ap.add_argument("--masks", default="0,1,2,4,3,7,8,16,24,25")
+    ap.add_argument("--masks", default="0,1,2,4,3,7,8,16,24,25")   # bit 32 + (n << 8): stagger by n x s_sleep(127)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--iters", type=int, default=5)
     args = ap.parse_args()

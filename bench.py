@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=256, help="256 = BASELINE configs[1]; 1024 = configs[4] at 8 GPUs")
     ap.add_argument("--frames", type=int, default=180)
     ap.add_argument("--graph", choices=["SHRE", "LMDHG"], default="SHRE")
-    ap.add_argument("--math", choices=["f32", "bf16x3", "bf16", "f32_valu"], default=os.environ.get("STGCN_MATH", "f32"))
+    ap.add_argument("--math", choices=["f32", "bf16x3", "bf16", "f32_valu"], default=os.environ.get("STGCN_MATH", "bf16x3"))
     ap.add_argument("--no-fuse", action="store_true", help="two-stage path (intermediate through HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=32)
@@ -113,12 +113,10 @@ def main():
     import stgcn_amd
     from stgcn_amd import functional as F
     stgcn_amd.lib()                                              # fail loudly before touching the GPU
+    from stgcn_amd import dist as sd
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)           # "nccl" is RCCL on ROCm
+    sd.init("nccl", dev)                                         # "nccl" is RCCL on ROCm; no-op at world 1
 
     T, V = args.frames, 22 if args.graph == "SHRE" else 46
     n_local = args.clips_per_gpu
@@ -129,25 +127,21 @@ def main():
     gcn, tcn = gcn.to(dev).eval(), tcn.to(dev).eval()
     if not args.no_fuse:
         stgcn_amd.enable_stem_fusion(gcn, tcn)
-    x = synthetic_clips(n_local, T, V, seed=rank).to(dev)        # resident in HBM before timing starts
-    stats = torch.zeros(3, device=dev)
+    x = synthetic_clips(n_local, T, V, seed=rank).to(dev)        # this rank's shard, resident in HBM before timing
+    stats = None
 
     def step():
+        nonlocal stats
         with torch.no_grad():
             out = tcn(gcn(x))
-        if dist is not None:
-            probe = out[:, :, 0, 0]
-            stats[0] = n_local
-            stats[1] = probe.sum()
-            stats[2] = probe.square().sum()
-            dist.all_reduce(stats)                               # tiny, latency-bound; RCCL over xGMI
+        if world > 1:                                            # tiny, latency-bound; RCCL over xGMI
+            stats = sd.all_reduce_stats(sd.step_stats(out, n_local))
         return out
 
     def fence():
         torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+        sd.barrier()
+        torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         out = step()
@@ -161,11 +155,10 @@ def main():
     elapsed = time.perf_counter() - t0
     F.kernel_timer = None
     kern_ms = timer.mean_ms("stem_tail")
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
+    elapsed = sd.max_over_ranks(elapsed, dev)
     assert torch.isfinite(out).all()
+    if stats is not None:
+        assert int(stats[0].item()) == n_local * world, "all-reduced clip count disagrees with the sharding"
 
     if rank == 0:
         clips_total = n_local * world * args.steps
@@ -177,7 +170,8 @@ def main():
             achieved = flops_clip * n_local / (kern_ms * 1e-3)
             peak = MFMA_PEAK[args.math]
             roof = {"bound": "mfma",
-                    "kernel": "stem_mfma_f32_kernel" if args.math == "f32" else "tcn_mfma_bf16_kernel<fused>",
+                    "kernel": "stem_mfma_f32_kernel" if args.math == "f32" else "stem_bf16_v4_kernel",
+                    "issued_over_algorithmic_flops": 3 if args.math == "bf16x3" else 1,
                     "achieved": round(achieved / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
                     "kernel_ms": round(kern_ms, 4), "launches_timed": timer.count("stem_tail"),
@@ -188,7 +182,9 @@ def main():
             "metric": "clips/sec ST-GCN forward", "value": round(value, 1), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.math.startswith("f32") else args.math,
+            "vs_baseline": None,
+            "dtype": {"f32": "f32", "f32_valu": "f32", "bf16": "bf16",
+                      "bf16x3": "bf16x3 (fp32 operands split hi+lo bf16, 3 MFMAs, fp32 accumulate)"}[args.math],
             "data": "synthetic randn clips (N,3,T,V), seeded random-init weights",
             "config": {"workload": f"SHREC'17-shape stem forward: V={V}, T={T}, {n_local} clips/GPU "
                                    f"(BASELINE configs[1] batch at 1 GPU; weak-scaled)",
@@ -200,8 +196,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     auto dma_stage = [&](int gs) {           // stage gs (taps 3gs..3gs+2 of the flat k index) -> ring slot gs&1
         char *dst = ring + (gs & 1) * STAGE_BYTES + wave * FRAG;
         const int gsm = gs % nstage;         // weights repeat for every tile
+        if (STGCN_ABL(64)) return;
 #pragma unroll
         for (int t = 0; t < STG; ++t) dma16(wsrc + (size_t)(gsm * STG + t) * 128, dst + t * 8 * FRAG);
     };
@@ -126,6 +127,10 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     if (tile < ntiles) zero_invalid_rows(tile);
     __syncthreads();
 
+#ifdef STGCN_ABLATION
+    if (STGCN_ABL(32))  // experiment: de-phase the CUs so their epilogue store bursts do not coincide
+        for (int i = 0; i < (int)(blockIdx.x & 7) * (abl >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+#endif
     int gs = 0;                               // running weight-stage counter (ring slot = gs & 1)
     const int h = lane >> 5;
     for (; tile < ntiles; tile += gridDim.x) {
@@ -161,7 +166,6 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             if (last && next_tile < ntiles) dma_features(next_tile);   // Fs is idle during the last chunk
 #pragma unroll
             for (int st = 0; st < KT4 / STG; ++st, ++gs) {
-                dma_stage(gs + 1);            // next stage -> other ring slot (its readers passed the last barrier)
                 const char *aslot = ring + (gs & 1) * STAGE_BYTES + (wm * 4) * FRAG + lane * 16;
 #pragma unroll
                 for (int tt = 0; tt < STG; ++tt) {
@@ -184,6 +188,9 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                         }
                     }
                     if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a, b);
+                    // next weight stage -> other ring slot (its readers passed the last barrier); issued behind the
+                    // first tap's MFMAs so the DMA's issue cost does not delay the start of the stage
+                    if (tt == 0) dma_stage(gs + 1);
                     if (tap < PB && !STGCN_ABL(1))  // (last chunk: recomputes chunk nch-1 into the idle buffer; discarded)
                         produce_block(nxt, min(ch + 1, nch - 1), min(wave + 8 * tap, nblk - 1));
                 }
@@ -191,19 +198,41 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             }
         }
 
-        // epilogue: D[row = channel][col = pixel], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        // epilogue: D[row = channel][col = pixel], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+        // Per-lane dword stores are store-issue-bound (measured ~7 B/clk/CU): transpose each 32-channel x 64-pixel
+        // block through this wave's 8 KiB slice of the (now idle) image buffers and store 16 B per lane, so one
+        // wave-instruction writes four 256-B channel rows.
         if (!STGCN_ABL(4)) {
+            float *stg = reinterpret_cast<float *>(buf0 + wave * 8192);
+            const int qw = g.q0 + wn * 64;                       // first pixel of this wave's 64 columns
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
+                const int ob = cg * 128 + (wm * 2 + m) * 32;     // first output channel of the block
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int o = cg * 128 + (wm * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const float sh = shift[o];
-                    const size_t base = ((size_t)n * C + o) * TV;
+                    const int cr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float sh = shift[ob + cr];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
-                        if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[m][j][r] + sh, 0.f));
+                    for (int j = 0; j < 2; ++j) stg[cr * 64 + j * 32 + (lane & 31)] = fmaxf(acc[m][j][r] + sh, 0.f);
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int idx = it * 64 + lane, row = idx >> 4, c4 = (idx & 15) * 4;
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + row * 64 + c4);
+                    const int q = qw + c4;
+                    const size_t gidx = ((size_t)n * C + ob + row) * TV + q;
+                    if (q + 3 <= g.q_last && (!BF16OUT || (gidx & 1) == 0)) {  // (bf16: keep the 8-B store dword-aligned)
+                        if constexpr (BF16OUT) {
+                            *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + gidx) =
+                                make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                        } else {
+                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + gidx) = v;
+                        }
+                    } else {                                     // ragged end of the clip
+                        const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (q + e <= g.q_last) store_out<BF16OUT>(y, gidx + e, e4[e]);
                     }
                 }
             }

@@ -1,0 +1,88 @@
+"""world_size-2 `gloo` tests of the data-parallel harness (CPU): sharding + the tiny stats all-reduce.
+
+The clip-sharded forward needs no collective; what is tested is that shards tile the batch exactly, that
+running the (CPU oracle) stem per shard and concatenating equals the single-rank result bit for bit, and
+that the all-reduced statistics equal the statistics of the whole batch.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (os.path.join(ROOT, "st-gcn-altformer_amd"), ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    from stgcn_amd import dist as sd
+    from _util import load_golden, sub_state
+    from oracle import stgcn_oracle as so
+    r, w = sd.init("gloo")
+    assert (r, w) == (rank, world)
+    g = load_golden("tcn_128_128_k9")
+    tp = so.tcn_params_from_state(sub_state(g, "tcn."))
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n_total, 128, 6, 22, generator=gen)                 # same batch on every rank
+    mine = sd.shard(x, rank, world)
+    out = so.tcn_forward(mine, tp)
+    stats = sd.all_reduce_stats(sd.step_stats(out, mine.shape[0]))
+    tmax = sd.max_over_ranks(0.1 * (rank + 1), torch.device("cpu"))
+    sd.barrier()
+    q.put((rank, sd.shard_bounds(n_total, rank, world), out, stats, tmax))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 7])
+def test_two_rank_sharding_and_stats(n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "st-gcn-altformer_amd"))
+    from stgcn_amd import dist as sd
+    from _util import load_golden, sub_state
+    from oracle import stgcn_oracle as so
+    # shards tile [0, n_total) exactly
+    assert res[0][1][0] == 0 and res[0][1][1] == res[1][1][0] and res[1][1][1] == n_total
+    g = load_golden("tcn_128_128_k9")
+    tp = so.tcn_params_from_state(sub_state(g, "tcn."))
+    x = torch.randn(n_total, 128, 6, 22, generator=torch.Generator().manual_seed(3))
+    full = so.tcn_forward(x, tp)
+    assert torch.equal(torch.cat([res[0][2], res[1][2]]), full)          # clip independence across ranks
+    ref = sd.step_stats(full, n_total)
+    for r in res:
+        assert torch.allclose(r[3], ref, rtol=1e-5, atol=1e-4)           # all-reduced == whole-batch statistics
+        assert r[3][0].item() == n_total
+        assert r[4] == pytest.approx(0.2)                                # MAX over ranks of the step time
+
+
+def test_shard_bounds_properties():
+    sys.path.insert(0, os.path.join(ROOT, "st-gcn-altformer_amd"))
+    from stgcn_amd.dist import shard_bounds
+    for n in (0, 1, 5, 8192, 8191):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)

@@ -91,6 +91,23 @@ def cpu_baseline(gcn, tcn, T, V, clips, reps):
                       f"oracle/stgcn_oracle.py fp32 torch-CPU"}
 
 
+def profiled_traffic(kernel_prefix, default_config):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/*_counters.json,
+    FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes; tools/collect_profiles.sh) — only for the default
+    workload those profiles were taken on; None otherwise."""
+    if not default_config:
+        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")), reverse=True):
+        try:
+            for name, m in json.load(open(path)).items():
+                if name.startswith(kernel_prefix) and "hbm_traffic_bytes_per_launch" in m:
+                    return int(m["hbm_traffic_bytes_per_launch"])
+        except (OSError, ValueError):
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,11 +186,12 @@ def main():
         if kern_ms:
             achieved = flops_clip * n_local / (kern_ms * 1e-3)
             peak = MFMA_PEAK[args.math]
-            roof = {"bound": "mfma",
-                    "kernel": "stem_mfma_f32_kernel" if args.math == "f32" else "stem_bf16_v4_kernel",
+            kname = "stem_mfma_f32_kernel" if args.math == "f32" else "stem_bf16_v4_kernel"
+            default_cfg = n_local == 256 and T == 180 and V == 22 and not args.no_fuse and args.math in ("bf16x3", "f32")
+            roof = {"bound": "mfma", "kernel": kname,
                     "issued_over_algorithmic_flops": 3 if args.math == "bf16x3" else 1,
                     "achieved": round(achieved / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": profiled_traffic(kname, default_cfg),
                     "kernel_ms": round(kern_ms, 4), "launches_timed": timer.count("stem_tail"),
                     "algorithmic_flops_per_launch": flops_clip * n_local,
                     "algorithmic_bytes_per_launch": bytes_clip * n_local,

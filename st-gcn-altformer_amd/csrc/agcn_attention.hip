@@ -49,14 +49,18 @@ __device__ __forceinline__ void softmax_columns_store(float *Sm, const float *__
     }
 }
 
-template <int MAXIT>
-__global__ __launch_bounds__(256) void attention_folded_kernel(
+// TS = time slices: 256*TS threads; slice ts accumulates the frames t = ts (mod TS) of the Gram, the partial
+// tiles are then summed through LDS.  More waves per CU matter here: the grid is only one workgroup per clip.
+template <int MAXIT, int TS>
+__global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
     const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
     float *__restrict__ P, float *__restrict__ feat, int Cin, int T, int V, int inter_c, int S, int TC,
     int Rp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NTH = 256 * TS;
     const int tid = threadIdx.x;
+    const int tl = tid & 255, ts = tid >> 8;  // Gram tile owner / time slice
     const int n = blockIdx.x;
     const int C1 = Cin + 1;
     const int R = Cin * V + 1;  // columns of X~ (last one is the constant 1)
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256) void attention_folded_kernel(
     float *U = smem + MS_FLOATS;  // Xs[TC][Rp] while accumulating, then Gs[R][R] + Sm[S][V][V]
 
     // M_s[k][l] = sum_c Wa~_s[c][k] * Wb~_s[c][l]   (bias folded in as column Cin)
-    for (int e = tid; e < S * C1 * C1; e += 256) {
+    for (int e = tid; e < S * C1 * C1; e += NTH) {
         const int s = e / (C1 * C1), kl = e - s * C1 * C1;
         const int k = kl / C1, l = kl - k * C1;
         float acc = 0.f;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void attention_folded_kernel(
     float acc[MAXIT][TM][TN];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-        const int t = tid + it * 256;
+        const int t = tl + it * 256;
         const int tt = (t < ntiles) ? t : 0;
         r0[it] = (tt / nTc) * TM;
         c0[it] = (tt % nTc) * TN;
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void attention_folded_kernel(
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int tc = min(TC, T - t0);
         __syncthreads();  // previous chunk fully consumed
-        for (int e = tid; e < TC * Rp; e += 256) {
+        for (int e = tid; e < TC * Rp; e += NTH) {
             const int tt = e / Rp, r = e - tt * Rp;
             float val = 0.f;
             if (tt < tc) {
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void attention_folded_kernel(
             U[e] = val;
         }
         __syncthreads();
-        for (int tt = 0; tt < tc; ++tt) {
+        for (int tt = ts; tt < tc; tt += TS) {
             const float *row = U + tt * Rp;
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it) {
@@ -131,19 +135,26 @@ __global__ __launch_bounds__(256) void attention_folded_kernel(
     __syncthreads();
     float *Gs = U;           // [R][R]
     float *Sm = U + R * R;   // [S][V][V]
+    for (int sl = 0; sl < TS; ++sl) {  // sum the TS partial Grams, one slice at a time
+        if (ts == sl) {
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-        if (tid + it * 256 < ntiles) {
+            for (int it = 0; it < MAXIT; ++it) {
+                if (tl + it * 256 < ntiles) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if (r0[it] + i < R && c0[it] + j < R) Gs[(r0[it] + i) * R + c0[it] + j] = acc[it][i][j];
+                        for (int j = 0; j < TN; ++j)
+                            if (r0[it] + i < R && c0[it] + j < R) {
+                                float *gp = Gs + (r0[it] + i) * R + c0[it] + j;
+                                *gp = (sl == 0) ? acc[it][i][j] : *gp + acc[it][i][j];
+                            }
+                }
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     const float denom = (float)(inter_c * T);  // A1.size(-1) at unit_agcn.py:84
-    for (int e = tid; e < S * V * V; e += 256) {
+    for (int e = tid; e < S * V * V; e += NTH) {
         const int s = e / (V * V), vw = e - s * V * V;
         const int v = vw / V, w = vw - v * V;
         const float *M = Ms + s * C1 * C1;
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256) void attention_folded_kernel(
         Sm[e] = sacc / denom;
     }
     __syncthreads();
-    softmax_columns_store(Sm, A_eff, P + (size_t)n * S * V * V, S, V, 0, tid, 256);
+    softmax_columns_store(Sm, A_eff, P + (size_t)n * S * V * V, S, V, 0, tid, NTH);
 
     // Optional feature pass for the fused stem (Cin = 3, S = 3 only): per pixel (t,w) the 12 graph-conv
     // features [u_0, u_1, u_2, x] with u_s[k] = sum_v x[k,t,v] P_s[v,w]  (model/unit_agcn.py:87-88), then a
@@ -171,12 +182,12 @@ __global__ __launch_bounds__(256) void attention_folded_kernel(
         const int tcf = min(TCF, T - t0);
         const int px = tcf * V;
         __syncthreads();  // P complete in Sm / previous chunk consumed
-        for (int e = tid; e < 3 * px; e += 256) {
+        for (int e = tid; e < 3 * px; e += NTH) {
             const int k = e / px, p = e - k * px;
             Xf[e] = xn[((size_t)k * T + t0) * V + p];
         }
         __syncthreads();
-        for (int p = tid; p < px; p += 256) {
+        for (int p = tid; p < px; p += NTH) {
             const int tt = p / V, w = p - tt * V;
             float u[9];
 #pragma unroll
@@ -305,16 +316,16 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
         if (u_floats < gs_floats) u_floats = gs_floats;
         const size_t lds = (MS_FLOATS + u_floats) * 4;
         const int maxit = ceil_div(ntiles, 256);
-#define LAUNCH_FOLDED(MI)                                                                     \
-    do {                                                                                      \
-        STGCN_HIP_CHECK(allow_lds(attention_folded_kernel<MI>, lds));                         \
-        hipLaunchKernelGGL(attention_folded_kernel<MI>, dim3(N), dim3(256), lds, st, x, A_eff, \
-                           Wa, ba, Wb, bb, P, feat, Cin, T, V, inter_c, S, TC, Rp);           \
+#define LAUNCH_FOLDED(MI, TSL)                                                                          \
+    do {                                                                                               \
+        STGCN_HIP_CHECK(allow_lds((attention_folded_kernel<MI, TSL>), lds));                           \
+        hipLaunchKernelGGL((attention_folded_kernel<MI, TSL>), dim3(N), dim3(256 * TSL), lds, st, x, A_eff, \
+                           Wa, ba, Wb, bb, P, feat, Cin, T, V, inter_c, S, TC, Rp);                    \
     } while (0)
-        if (maxit <= 1) LAUNCH_FOLDED(1);
-        else if (maxit <= 2) LAUNCH_FOLDED(2);
-        else if (maxit <= 4) LAUNCH_FOLDED(4);
-        else LAUNCH_FOLDED(8);
+        if (maxit <= 1) LAUNCH_FOLDED(1, 4);
+        else if (maxit <= 2) LAUNCH_FOLDED(2, 4);
+        else if (maxit <= 4) LAUNCH_FOLDED(4, 4);
+        else LAUNCH_FOLDED(8, 2);
 #undef LAUNCH_FOLDED
         STGCN_LAUNCH_CHECK("attention_folded_kernel");
         return STGCN_OK;

@@ -42,6 +42,16 @@ static inline int ablate_mask() {
 #endif
 }
 
+// diagnostic builds: device buffer for in-kernel cycle stamps (address in env STGCN_DBG_PTR), else NULL
+static inline unsigned long long *debug_buffer() {
+#ifdef STGCN_ABLATION
+    const char *e = getenv("STGCN_DBG_PTR");
+    return e ? reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0)) : nullptr;
+#else
+    return nullptr;
+#endif
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 

@@ -36,15 +36,34 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-__device__ __forceinline__ void dma16(const void *g, void *l) {  // 64 lanes x 16 B -> LDS at l + lane*16
-    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+// LDS-DMA: 64 lanes x 16 B -> LDS at l (wave-uniform) + lane*16.  Issued through inline asm on purpose: with the
+// builtin hipcc (ROCm 7.2) treats the DMA as a pending LDS write that any later ds_read may alias and puts
+// `s_waitcnt vmcnt(0)` in front of the very next ds_read — the whole DMA latency exposed every stage (measured
+// ~270 cycles per DMA instruction).  An asm DMA is invisible to that bookkeeping; dma_wait() before the stage
+// barrier is then OUR job (vmcnt is in order, so the compiler's own counted waits only get stricter).
+__device__ __forceinline__ void dma16(const void *g, unsigned lds_addr) {  // lds_addr: LDS byte address, wave-uniform
+    const unsigned lds = __builtin_amdgcn_readfirstlane(lds_addr);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds)
+                 : "memory");
 }
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int PB, int TERMS, bool BF16OUT>
 __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     const float4 *__restrict__ feat, const float *__restrict__ W12, const uint4 *__restrict__ Wp,
     const float *__restrict__ shift, void *y, int C, int T, int V, int ROWS, int tiles_per_clip, int ntiles,
-    int abl) {
+    int abl, unsigned long long *dbg) {
+#ifdef STGCN_ABLATION  // in-kernel cycle stamps (diagnostic builds only; dbg == NULL otherwise)
+#define STGCN_STAMP(var) unsigned long long var = 0; if (dbg) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); }
+#define STGCN_ACC(slot, a, b) if (dbg) { tsum[slot] += (b) - (a); }
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+#define STGCN_STAMP(var)
+#define STGCN_ACC(slot, a, b)
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem4[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -61,12 +80,16 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     char *buf0 = ring + 2 * STAGE_BYTES;
     char *buf1 = buf0 + buf_bytes;
     float4 *Fs = reinterpret_cast<float4 *>(buf1 + buf_bytes);      // 4 planes of [ROWS] float4
+    // LDS byte addresses for the DMA destinations (M0), derived from the array base by plain arithmetic
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem4;
+    const unsigned ring_lds = lds0 + (unsigned)(ring - smem4);
+    const unsigned fs_lds = lds0 + (unsigned)(reinterpret_cast<char *>(Fs) - smem4);
 
     const int cg = blockIdx.y;               // 128-channel group of the output
     // weight fragment this wave DMAs each tap: f = wave -> m-block (f>>1), image (f&1)
     const uint4 *wsrc = Wp + ((size_t)(cg * 4 + (wave >> 1)) * nch * KT4 * 2 + (wave & 1)) * 64 + lane;
     auto dma_stage = [&](int gs) {           // stage gs (taps 3gs..3gs+2 of the flat k index) -> ring slot gs&1
-        char *dst = ring + (gs & 1) * STAGE_BYTES + wave * FRAG;
+        const unsigned dst = ring_lds + (gs & 1) * STAGE_BYTES + wave * FRAG;
         const int gsm = gs % nstage;         // weights repeat for every tile
         if (STGCN_ABL(64)) return;
 #pragma unroll
@@ -81,7 +104,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             const int q = c / ROWS, j = c - q * ROWS + lane;       // ROWS % 64 == 0
             int gi = g.origin + j;
             gi = max(0, min(gi, TV - 1));
-            dma16(src + (size_t)gi * 4 + q, reinterpret_cast<char *>(Fs + (size_t)q * ROWS + (c - q * ROWS)));
+            dma16(src + (size_t)gi * 4 + q, fs_lds + (unsigned)(q * ROWS + (c - q * ROWS)) * 16u);
         }
     };
     auto zero_invalid_rows = [&](int tile) {
@@ -97,19 +120,21 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     };
 
     // ---- producer: one 16-pixel block of chunk `ch` -> hi/lo images of `buf` -------------------
+    // Split in three so that the main loop can software-pipeline it: operands (two ds_read_b128), four chained
+    // v_mfma_f32_16x16x4_f32 (each placed between groups of consumer MFMAs, hiding the 40-cycle dependent
+    // latency), and the finish (ReLU, hi/lo split, two 8-byte LDS stores) one tap later.
     const int pl = lane & 15, pg = lane >> 4;
-    auto produce_block = [&](char *buf, int ch, int bi) {
-        const int p = bi * 16 + pl;
-        const float4 wa = *reinterpret_cast<const float4 *>(W12s + (ch * CCB + pl) * W12P + 4 * pg);
-        const float4 fb = Fs[(size_t)pg * ROWS + p];
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, fb.x, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, fb.y, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, fb.z, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, fb.w, d, 0, 0, 0);
-        const float v0 = fmaxf(d[0], 0.f), v1 = fmaxf(d[1], 0.f), v2 = fmaxf(d[2], 0.f), v3 = fmaxf(d[3], 0.f);
+    struct Prod { float4 wa, fb; f32x4 d; int p; };
+    auto prod_load = [&](Prod &pr, int ch, int bi) {
+        pr.p = bi * 16 + pl;
+        pr.wa = *reinterpret_cast<const float4 *>(W12s + (ch * CCB + pl) * W12P + 4 * pg);
+        pr.fb = Fs[(size_t)pg * ROWS + pr.p];
+        pr.d = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto prod_finish = [&](char *buf, const Prod &pr) {
+        const float v0 = fmaxf(pr.d[0], 0.f), v1 = fmaxf(pr.d[1], 0.f), v2 = fmaxf(pr.d[2], 0.f), v3 = fmaxf(pr.d[3], 0.f);
         const unsigned h0 = pack_bf16x2(v0, v1), h1 = pack_bf16x2(v2, v3);
-        const int off = lds_off(p, pg >> 1) + (pg & 1) * 8;
+        const int off = lds_off(pr.p, pg >> 1) + (pg & 1) * 8;
         *reinterpret_cast<uint2 *>(buf + off) = make_uint2(h0, h1);
         if constexpr (TERMS == 3) {
             const unsigned l0 = pack_bf16x2(v0 - bf16_lo_to_f32(h0), v1 - bf16_hi_to_f32(h0));
@@ -117,12 +142,34 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             *reinterpret_cast<uint2 *>(buf + img_bytes + off) = make_uint2(l0, l1);
         }
     };
+    auto produce_block = [&](char *buf, int ch, int bi) {  // un-pipelined form (chunk 0 of a tile)
+        Prod pr;
+        prod_load(pr, ch, bi);
+        pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.x, pr.fb.x, pr.d, 0, 0, 0);
+        pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.y, pr.fb.y, pr.d, 0, 0, 0);
+        pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.z, pr.fb.z, pr.d, 0, 0, 0);
+        pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.w, pr.fb.w, pr.d, 0, 0, 0);
+        prod_finish(buf, pr);
+    };
+    // consumer MFMAs of one (channel block m, pixel block n) pair
+    auto mfma_pair = [&](f32x16 &c, const Frag2<TERMS> &a, const Frag2<TERMS> &b, int m, int nb) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, a.hi[m]);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi[nb]);
+        if constexpr (TERMS == 3) {
+            const bf16x8 al = __builtin_bit_cast(bf16x8, a.lo[m]);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, b.lo[nb]);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    };
 
     // ---- one-time setup ----------------------------------------------------------------------
     for (int e = tid; e < C * W12P; e += NT4) W12s[e] = W12[e];
     int tile = blockIdx.x;
     if (tile < ntiles) dma_features(tile);
     dma_stage(0);
+    dma_wait();
     __syncthreads();                          // W12s, Fs(tile), weight stage 0 landed
     if (tile < ntiles) zero_invalid_rows(tile);
     __syncthreads();
@@ -139,6 +186,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         const int nblk = (g.span + 15) >> 4;
         const int next_tile = tile + gridDim.x;
 
+        STGCN_STAMP(t_tile0)
         // chunk 0 of this tile
         for (int b = wave; b < nblk; b += 8) produce_block(buf0, 0, b);
 
@@ -158,7 +206,10 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
         __syncthreads();                      // chunk 0 visible
+        STGCN_STAMP(t_tile1)
+        STGCN_ACC(0, t_tile0, t_tile1)
 
+        Prod pr = {};
         for (int ch = 0; ch < nch; ++ch) {
             const char *cur = (ch & 1) ? buf1 : buf0;
             char *nxt = (ch & 1) ? buf0 : buf1;
@@ -166,6 +217,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             if (last && next_tile < ntiles) dma_features(next_tile);   // Fs is idle during the last chunk
 #pragma unroll
             for (int st = 0; st < KT4 / STG; ++st, ++gs) {
+                STGCN_STAMP(t_s0)
                 const char *aslot = ring + (gs & 1) * STAGE_BYTES + (wm * 4) * FRAG + lane * 16;
 #pragma unroll
                 for (int tt = 0; tt < STG; ++tt) {
@@ -187,14 +239,31 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                             if constexpr (TERMS == 3) b.lo[j] = *reinterpret_cast<const uint4 *>(cur + img_bytes + off);
                         }
                     }
-                    if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a, b);
+                    const bool prod = tap < PB && !STGCN_ABL(1);
+                    // finish the block whose MFMAs ran during the previous tap, then start this tap's block
+                    if (tap >= 1 && tap <= PB && !STGCN_ABL(1)) prod_finish(nxt, pr);
+                    if (prod) prod_load(pr, min(ch + 1, nch - 1), min(wave + 8 * tap, nblk - 1));  // (last chunk: discarded)
+                    if (!STGCN_ABL(2)) {
+                        mfma_pair(acc[0][0], a, b, 0, 0);
+                        if (prod) pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.x, pr.fb.x, pr.d, 0, 0, 0);
+                        mfma_pair(acc[0][1], a, b, 0, 1);
+                        if (prod) pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.y, pr.fb.y, pr.d, 0, 0, 0);
+                        mfma_pair(acc[1][0], a, b, 1, 0);
+                        if (prod) pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.z, pr.fb.z, pr.d, 0, 0, 0);
+                        mfma_pair(acc[1][1], a, b, 1, 1);
+                        if (prod) pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.w, pr.fb.w, pr.d, 0, 0, 0);
+                    }
                     // next weight stage -> other ring slot (its readers passed the last barrier); issued behind the
                     // first tap's MFMAs so the DMA's issue cost does not delay the start of the stage
                     if (tt == 0) dma_stage(gs + 1);
-                    if (tap < PB && !STGCN_ABL(1))  // (last chunk: recomputes chunk nch-1 into the idle buffer; discarded)
-                        produce_block(nxt, min(ch + 1, nch - 1), min(wave + 8 * tap, nblk - 1));
+                    if (PB == KT4 && tap == KT4 - 1 && !STGCN_ABL(1)) prod_finish(nxt, pr);  // no later tap to finish in
                 }
+                STGCN_STAMP(t_s1)
+                dma_wait();
                 __syncthreads();              // stage done: next weights landed (vmcnt 0) and visible; chunk boundary at st==2
+                STGCN_STAMP(t_s2)
+                STGCN_ACC(1, t_s0, t_s1)
+                STGCN_ACC(2, t_s1, t_s2)
             }
         }
 
@@ -202,6 +271,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         // Per-lane dword stores are store-issue-bound (measured ~7 B/clk/CU): transpose each 32-channel x 64-pixel
         // block through this wave's 8 KiB slice of the (now idle) image buffers and store 16 B per lane, so one
         // wave-instruction writes four 256-B channel rows.
+        STGCN_STAMP(t_e0)
         if (!STGCN_ABL(4)) {
             float *stg = reinterpret_cast<float *>(buf0 + wave * 8192);
             const int qw = g.q0 + wn * 64;                       // first pixel of this wave's 64 columns
@@ -237,11 +307,19 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                 }
             }
         }
+        STGCN_STAMP(t_e1)
+        STGCN_ACC(3, t_e0, t_e1)
         if (next_tile < ntiles) {             // its feature rows landed at the last stage barrier
             zero_invalid_rows(next_tile);
             __syncthreads();
         }
+        STGCN_STAMP(t_e2)
+        STGCN_ACC(4, t_e1, t_e2)
     }
+#ifdef STGCN_ABLATION
+    if (dbg && lane == 0 && blockIdx.x < 8 && blockIdx.y == 0)
+        for (int i = 0; i < 8; ++i) dbg[(blockIdx.x * 8 + wave) * 8 + i] = tsum[i];
+#endif
 }
 
 struct V4Plan {
@@ -277,12 +355,12 @@ int launch_v4(const float4 *feat, const float *W12, const uint4 *Wp, const float
         auto kern = stem_bf16_v4_kernel<PB, TERMS, true>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
-                           pl.tiles_per_clip, ntiles, ablate_mask());
+                           pl.tiles_per_clip, ntiles, ablate_mask(), debug_buffer());
     } else {
         auto kern = stem_bf16_v4_kernel<PB, TERMS, false>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
-                           pl.tiles_per_clip, ntiles, ablate_mask());
+                           pl.tiles_per_clip, ntiles, ablate_mask(), debug_buffer());
     }
     STGCN_LAUNCH_CHECK("stem_bf16_v4_kernel");
     return STGCN_OK;

@@ -131,9 +131,12 @@ def main():
     from stgcn_amd import functional as F
     stgcn_amd.lib()                                              # fail loudly before touching the GPU
     from stgcn_amd import dist as sd
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    sd.init("nccl", dev)                                         # "nccl" is RCCL on ROCm; no-op at world 1
+    # one rank per GPU; STGCN_DIST_BACKEND=gloo + fewer GPUs than ranks is a rehearsal mode for 1-GPU boxes only
+    backend = os.environ.get("STGCN_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    sd.init(backend, dev)                                        # no-op at world 1
 
     T, V = args.frames, 22 if args.graph == "SHRE" else 46
     n_local = args.clips_per_gpu

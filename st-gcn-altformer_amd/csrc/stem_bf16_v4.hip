@@ -120,9 +120,9 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     };
 
     // ---- producer: one 16-pixel block of chunk `ch` -> hi/lo images of `buf` -------------------
-    // Split in three so that the main loop can software-pipeline it: operands (two ds_read_b128), four chained
-    // v_mfma_f32_16x16x4_f32 (each placed between groups of consumer MFMAs, hiding the 40-cycle dependent
-    // latency), and the finish (ReLU, hi/lo split, two 8-byte LDS stores) one tap later.
+    // operands (two ds_read_b128), four chained v_mfma_f32_16x16x4_f32, then ReLU, hi/lo split and two 8-byte LDS
+    // stores.  (Spreading the four MFMAs between the consumer MFMAs and finishing a tap later was measured 3 %
+    // slower: more live registers, same pipe time.)
     const int pl = lane & 15, pg = lane >> 4;
     struct Prod { float4 wa, fb; f32x4 d; int p; };
     auto prod_load = [&](Prod &pr, int ch, int bi) {
@@ -151,19 +151,6 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.w, pr.fb.w, pr.d, 0, 0, 0);
         prod_finish(buf, pr);
     };
-    // consumer MFMAs of one (channel block m, pixel block n) pair
-    auto mfma_pair = [&](f32x16 &c, const Frag2<TERMS> &a, const Frag2<TERMS> &b, int m, int nb) {
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, a.hi[m]);
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi[nb]);
-        if constexpr (TERMS == 3) {
-            const bf16x8 al = __builtin_bit_cast(bf16x8, a.lo[m]);
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, b.lo[nb]);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-        }
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-    };
-
     // ---- one-time setup ----------------------------------------------------------------------
     for (int e = tid; e < C * W12P; e += NT4) W12s[e] = W12[e];
     int tile = blockIdx.x;
@@ -177,6 +164,9 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
 #ifdef STGCN_ABLATION
     if (STGCN_ABL(32))  // experiment: de-phase the CUs so their epilogue store bursts do not coincide
         for (int i = 0; i < (int)(blockIdx.x & 7) * (abl >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+#endif
+#ifdef STGCN_ABLATION
+    if (STGCN_ABL(128) && wave >= 4) __builtin_amdgcn_s_setprio(1);  // experiment: static priority for the younger half
 #endif
     int gs = 0;                               // running weight-stage counter (ring slot = gs & 1)
     const int h = lane >> 5;
@@ -209,7 +199,6 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         STGCN_STAMP(t_tile1)
         STGCN_ACC(0, t_tile0, t_tile1)
 
-        Prod pr = {};
         for (int ch = 0; ch < nch; ++ch) {
             const char *cur = (ch & 1) ? buf1 : buf0;
             char *nxt = (ch & 1) ? buf0 : buf1;
@@ -239,24 +228,12 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                             if constexpr (TERMS == 3) b.lo[j] = *reinterpret_cast<const uint4 *>(cur + img_bytes + off);
                         }
                     }
-                    const bool prod = tap < PB && !STGCN_ABL(1);
-                    // finish the block whose MFMAs ran during the previous tap, then start this tap's block
-                    if (tap >= 1 && tap <= PB && !STGCN_ABL(1)) prod_finish(nxt, pr);
-                    if (prod) prod_load(pr, min(ch + 1, nch - 1), min(wave + 8 * tap, nblk - 1));  // (last chunk: discarded)
-                    if (!STGCN_ABL(2)) {
-                        mfma_pair(acc[0][0], a, b, 0, 0);
-                        if (prod) pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.x, pr.fb.x, pr.d, 0, 0, 0);
-                        mfma_pair(acc[0][1], a, b, 0, 1);
-                        if (prod) pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.y, pr.fb.y, pr.d, 0, 0, 0);
-                        mfma_pair(acc[1][0], a, b, 1, 0);
-                        if (prod) pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.z, pr.fb.z, pr.d, 0, 0, 0);
-                        mfma_pair(acc[1][1], a, b, 1, 1);
-                        if (prod) pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.w, pr.fb.w, pr.d, 0, 0, 0);
-                    }
+                    if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a, b);
                     // next weight stage -> other ring slot (its readers passed the last barrier); issued behind the
                     // first tap's MFMAs so the DMA's issue cost does not delay the start of the stage
                     if (tt == 0) dma_stage(gs + 1);
-                    if (PB == KT4 && tap == KT4 - 1 && !STGCN_ABL(1)) prod_finish(nxt, pr);  // no later tap to finish in
+                    if (tap < PB && !STGCN_ABL(1))  // (last chunk: recomputes chunk nch-1 into the idle buffer; discarded)
+                        produce_block(nxt, min(ch + 1, nch - 1), min(wave + 8 * tap, nblk - 1));
                 }
                 STGCN_STAMP(t_s1)
                 dma_wait();

@@ -145,6 +145,14 @@ int stgcn_stem_forward_prepared(const float *x, const float *A_eff, const float 
                                 void *out, int N, int Cin, int C, int T, int V, int inter_c,
                                 int subsets, int K, unsigned flags, void *stream);
 
+/* ---- data-parallel harness -------------------------------------------------------------------
+ * Per-rank reductions that the ranks all-reduce once per step (the data-parallel form of the
+ * reference's accuracy reduction, SHREC/ST_TS/train_sttran.py:105-109): stats[0] = n_local,
+ * stats[1] = sum probe, stats[2] = sum probe^2, stats[3] = 0, with probe[n][c] = out[n][c][0][0]
+ * (`plane` = T*V elements between consecutive (n,c) planes).  One launch, one workgroup. */
+int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int C, long plane,
+                     float n_local, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,35 @@ __global__ void bn_fold_kernel(const float *__restrict__ w, const float *__restr
     shift[c] = fmaf(centre, s, b[c]);
 }
 
+// per-rank reductions for the data-parallel harness: stats = [clips, sum(probe), sum(probe^2), 0] with
+// probe[n][c] = out[n][c][0][0]; one workgroup, one launch (replaces ~6 tiny torch kernels per step)
+template <bool BF16>
+__global__ __launch_bounds__(256) void step_stats_kernel(const void *__restrict__ out, float *__restrict__ stats,
+                                                          int NC, size_t plane, float n_local) {
+    __shared__ float red[2][4];
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = threadIdx.x; e < NC; e += 256) {
+        float v;
+        if constexpr (BF16) v = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(out)[(size_t)e * plane] << 16);
+        else v = reinterpret_cast<const float *>(out)[(size_t)e * plane];
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o, 64);
+        s2 += __shfl_down(s2, o, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        stats[0] = n_local;
+        stats[1] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        stats[2] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        stats[3] = 0.f;
+    }
+}
+
 }  // namespace
 
 int launch_bn_fold(const float *w, const float *b, const float *rm, const float *rv, const float *cb,
@@ -207,6 +236,19 @@ int stgcn_stem_forward_prepared(const float *x, const float *A_eff, const float 
                                   stream);
     if (rc != STGCN_OK) return rc;
     return stgcn_stem_tail_prepared(x, ws, ws_bytes, prep, t_shift, out, N, Cin, C, T, V, subsets, K, flags, stream);
+}
+
+int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int C, long plane, float n_local,
+                     void *stream) {
+    REQUIRE_PTR(out); REQUIRE_PTR(stats); REQUIRE_POS(N); REQUIRE_POS(C); REQUIRE_POS(plane);
+    if (out_is_bf16)
+        hipLaunchKernelGGL(step_stats_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, out, stats, N * C,
+                           (size_t)plane, n_local);
+    else
+        hipLaunchKernelGGL(step_stats_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)stream, out, stats, N * C,
+                           (size_t)plane, n_local);
+    STGCN_LAUNCH_CHECK("step_stats_kernel");
+    return STGCN_OK;
 }
 
 }  // extern "C"

@@ -47,6 +47,17 @@ def shard(batch: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 def step_stats(out: torch.Tensor, n_local: int, logits: Optional[torch.Tensor] = None,
                labels: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Per-rank reductions to all-reduce: [clips, sum(probe), sum(probe^2), correct]."""
+    if out.is_cuda and logits is None and out.is_contiguous() and out.dtype in (torch.float32, torch.bfloat16):
+        # one HIP launch on the current stream (stgcn_step_stats) instead of half a dozen tiny torch kernels
+        from ctypes import c_float, c_int, c_long, c_void_p
+        from . import _capi
+        stats = torch.empty(4, device=out.device, dtype=torch.float32)
+        plane = out[0, 0].numel()
+        with torch.cuda.device(out.device):
+            _capi.call("stgcn_step_stats", c_void_p(out.data_ptr()), c_int(out.dtype == torch.bfloat16),
+                       c_void_p(stats.data_ptr()), c_int(out.shape[0]), c_int(out.shape[1]), c_long(plane),
+                       c_float(float(n_local)), c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
+        return stats
     probe = out.reshape(out.shape[0], out.shape[1], -1)[:, :, 0].float()
     correct = out.new_zeros((), dtype=torch.float32)
     if logits is not None and labels is not None:

@@ -308,3 +308,17 @@ def test_stem_forward_prepared_entry_point(dev):
                c_void_p(torch.cuda.current_stream().cuda_stream))
     parity_gate(ws[:x.shape[0] * 3 * 22 * 22].view(-1, 3, 22, 22), gcn.last_attention, 1e-6, "P in workspace")
     assert torch.equal(out, ref)
+
+
+def test_step_stats_kernel_matches_torch(dev):
+    """stgcn_step_stats (the per-rank reduction that is all-reduced each step) equals the torch formulation."""
+    from stgcn_amd import dist as sd
+    gen = torch.Generator().manual_seed(5)
+    out = torch.randn(37, 128, 6, 22, generator=gen).to(dev)
+    got = sd.step_stats(out, 37).cpu()
+    probe = out[:, :, 0, 0].double().cpu()
+    ref = torch.tensor([37.0, probe.sum().item(), probe.square().sum().item(), 0.0])
+    assert torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-3)
+    got16 = sd.step_stats(out.to(torch.bfloat16), 37).cpu()
+    p16 = out.to(torch.bfloat16)[:, :, 0, 0].double().cpu()
+    assert torch.allclose(got16[1:3].double(), torch.tensor([p16.sum().item(), p16.square().sum().item()]), rtol=1e-4, atol=1e-2)

@@ -189,12 +189,17 @@ def main():
         if kern_ms:
             achieved = flops_clip * n_local / (kern_ms * 1e-3)
             peak = MFMA_PEAK[args.math]
-            kname = "stem_mfma_f32_kernel" if args.math == "f32" else "stem_bf16_v4_kernel"
+            from stgcn_amd import _capi
+            v4 = args.math in ("bf16x3", "bf16") and bool(_capi.lib().stgcn_stem_features_used(3, 128, T, V, 9, 3, F._flags(
+                {"bf16x3": F.MATH_BF16X3, "bf16": F.MATH_BF16}.get(args.math, 0), False)))
+            kname = "stem_mfma_f32_kernel" if args.math == "f32" else ("stem_bf16_v4_kernel" if v4 else "stem_mfma_bf16_kernel")
+            peak_f32 = MFMA_PEAK["f32"]
             default_cfg = n_local == 256 and T == 180 and V == 22 and not args.no_fuse and args.math in ("bf16x3", "f32")
             roof = {"bound": "mfma", "kernel": kname,
                     "issued_over_algorithmic_flops": 3 if args.math == "bf16x3" else 1,
                     "achieved": round(achieved / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": profiled_traffic(kname, default_cfg),
+                    "achieved_over_f32_matrix_peak": round(achieved / peak_f32, 3),
                     "kernel_ms": round(kern_ms, 4), "launches_timed": timer.count("stem_tail"),
                     "algorithmic_flops_per_launch": flops_clip * n_local,
                     "algorithmic_bytes_per_launch": bytes_clip * n_local,

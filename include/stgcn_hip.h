@@ -129,6 +129,8 @@ int stgcn_stem_prepare(const float *Wd, const float *bd, const float *Wdown, con
  * P (N,S,V,V) at offset 0 (valid on return) followed by per-pixel graph-conv features for the kernels
  * that consume them. */
 size_t stgcn_stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int subsets, unsigned flags);
+/* 1 when the large-tile persistent kernel (which reads the feature part of the workspace) serves the shape */
+int stgcn_stem_features_used(int Cin, int C, int T, int V, int K, int subsets, unsigned flags);
 /* The two halves of stgcn_stem_forward_prepared, separately launchable (e.g. to time them):
  * stgcn_stem_attention fills the workspace; stgcn_stem_tail_prepared launches only the fused
  * graph-conv + temporal-conv kernel on a filled workspace. */

@@ -201,6 +201,11 @@ size_t stgcn_stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int subse
     return stem_ws_bytes(N, Cin, C, T, V, K, subsets, flags);
 }
 
+int stgcn_stem_features_used(int Cin, int C, int T, int V, int K, int subsets, unsigned flags) {
+    if (Cin <= 0 || C <= 0 || T <= 0 || V <= 0 || K <= 0 || subsets <= 0) return 0;
+    return stem_v4_supported(Cin, C, T, V, K, subsets, flags) ? 1 : 0;
+}
+
 int stgcn_stem_attention(const float *x, const float *A_eff, const float *Wa, const float *ba, const float *Wb,
                          const float *bb, void *ws, size_t ws_bytes, int N, int Cin, int C, int T, int V,
                          int inter_c, int subsets, int K, unsigned flags, void *stream) {

@@ -232,6 +232,8 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                     // next weight stage -> other ring slot (its readers passed the last barrier); issued behind the
                     // first tap's MFMAs so the DMA's issue cost does not delay the start of the stage
                     if (tt == 0) dma_stage(gs + 1);
+                    // (Giving waves 4-7 their producer blocks / DMA at other taps than waves 0-3, and a static s_setprio
+                    //  for that half, were both measured neutral-to-negative.)
                     if (tap < PB && !STGCN_ABL(1))  // (last chunk: recomputes chunk nch-1 into the idle buffer; discarded)
                         produce_block(nxt, min(ch + 1, nch - 1), min(wave + 8 * tap, nblk - 1));
                 }

@@ -317,8 +317,9 @@ def test_step_stats_kernel_matches_torch(dev):
     out = torch.randn(37, 128, 6, 22, generator=gen).to(dev)
     got = sd.step_stats(out, 37).cpu()
     probe = out[:, :, 0, 0].double().cpu()
-    ref = torch.tensor([37.0, probe.sum().item(), probe.square().sum().item(), 0.0])
+    ref = torch.tensor([37.0, probe.sum().item(), probe.square().sum().item(), 0.0], dtype=torch.float64)
     assert torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-3)
     got16 = sd.step_stats(out.to(torch.bfloat16), 37).cpu()
     p16 = out.to(torch.bfloat16)[:, :, 0, 0].double().cpu()
-    assert torch.allclose(got16[1:3].double(), torch.tensor([p16.sum().item(), p16.square().sum().item()]), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(got16[1:3].double(), torch.tensor([p16.sum().item(), p16.square().sum().item()], dtype=torch.float64),
+                          rtol=1e-4, atol=1e-2)

@@ -56,9 +56,15 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
     const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
     float *__restrict__ P, float *__restrict__ feat, int Cin, int T, int V, int inter_c, int S, int TC,
-    int Rp) {
+    int Rp, int feat_slice_off, unsigned long long *dbg) {
+#ifdef STGCN_ABLATION  // in-kernel cycle stamps (diagnostic builds only)
+#define K1_STAMP(i) if (dbg && threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dbg[1024 + (i)] = t_; }
+#else
+#define K1_STAMP(i)
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NTH = 256 * TS;
+    K1_STAMP(0)
     const int tid = threadIdx.x;
     const int tl = tid & 255, ts = tid >> 8;  // Gram tile owner / time slice
     const int n = blockIdx.x;
@@ -67,18 +73,30 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     float *Ms = smem;
     float *U = smem + MS_FLOATS;  // Xs[TC][Rp] while accumulating, then Gs[R][R] + Sm[S][V][V]
 
-    // M_s[k][l] = sum_c Wa~_s[c][k] * Wb~_s[c][l]   (bias folded in as column Cin)
-    for (int e = tid; e < S * C1 * C1; e += NTH) {
-        const int s = e / (C1 * C1), kl = e - s * C1 * C1;
-        const int k = kl / C1, l = kl - k * C1;
-        float acc = 0.f;
-        for (int c = 0; c < inter_c; ++c) {
-            const int row = s * inter_c + c;
-            const float wa = (k < Cin) ? Wa[row * Cin + k] : ba[row];
-            const float wb = (l < Cin) ? Wb[row * Cin + l] : bb[row];
-            acc = fmaf(wa, wb, acc);
+    // M_s[k][l] = sum_c Wa~_s[c][k] * Wb~_s[c][l]   (bias folded in as column Cin).  The embedding weights are first
+    // copied to LDS (coalesced) so the 48 dot products do not each chain 64 dependent global loads.
+    {
+        const int rows = S * inter_c;
+        float *Wl = U;  // [2][rows][C1]  (U is free until the first clip chunk is staged)
+        for (int e = tid; e < 2 * rows * C1; e += NTH) {
+            const int ab = e / (rows * C1), rc = e - ab * rows * C1;
+            const int row = rc / C1, k = rc - row * C1;
+            const float *W = ab ? Wb : Wa;
+            const float *bv = ab ? bb : ba;
+            Wl[e] = (k < Cin) ? W[row * Cin + k] : bv[row];
         }
-        Ms[e] = acc;
+        __syncthreads();
+        for (int e = tid; e < S * C1 * C1; e += NTH) {
+            const int s = e / (C1 * C1), kl = e - s * C1 * C1;
+            const int k = kl / C1, l = kl - k * C1;
+            float acc = 0.f;
+            for (int c = 0; c < inter_c; ++c) {
+                const int row = s * inter_c + c;
+                acc = fmaf(Wl[row * C1 + k], Wl[(rows + row) * C1 + l], acc);
+            }
+            Ms[e] = acc;
+        }
+        // (the first __syncthreads() of the chunk loop below orders these reads before U is overwritten)
     }
 
     const int nTr = (R + TM - 1) / TM, nTc = (R + TN - 1) / TN;
@@ -99,24 +117,37 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
 
     const float *xn = x + (size_t)n * Cin * T * V;
     const int CV = Cin * V;
+    K1_STAMP(1)
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int tc = min(TC, T - t0);
         __syncthreads();  // previous chunk fully consumed
-        for (int e = tid; e < TC * Rp; e += NTH) {
-            const int tt = e / Rp, r = e - tt * Rp;
-            float val = 0.f;
-            if (tt < tc) {
-                if (r < CV) {
-                    const int k = r / V, v = r - k * V;
-                    val = xn[((size_t)k * T + (t0 + tt)) * V + v];
-                } else if (r == CV) {
-                    val = 1.f;
+        // padding columns (zeros) and the constant-1 column: TC * (Rp - CV) entries
+        {
+            const int padw = Rp - CV;
+            for (int e = tid; e < TC * padw; e += NTH) {
+                const int tt = e / padw, r = CV + (e - tt * padw);
+                U[tt * Rp + r] = (r == CV && tt < tc) ? 1.f : 0.f;
+            }
+        }
+        // data columns: channel k, frame tt, joint v  <-  x[k][t0+tt][v]; (tt,v) advanced incrementally (no division)
+        {
+            const int stepT = NTH / V, stepV = NTH - stepT * V;
+            const int tt0 = tid / V, v0 = tid - tt0 * V;
+            for (int k = 0; k < Cin; ++k) {
+                const float *xk = xn + ((size_t)k * T + t0) * V;
+                int tt = tt0, v = v0;
+                for (int e = tid; e < TC * V; e += NTH) {
+                    U[tt * Rp + k * V + v] = (tt < tc) ? xk[e] : 0.f;
+                    tt += stepT;
+                    v += stepV;
+                    if (v >= V) { v -= V; ++tt; }
                 }
             }
-            U[e] = val;
         }
         __syncthreads();
-        for (int tt = ts; tt < tc; tt += TS) {
+        K1_STAMP(2)
+#pragma unroll 4
+        for (int tt = ts; tt < tc; tt += TS) {  // (unrolled: the LDS reads of later frames overlap the FMAs)
             const float *row = U + tt * Rp;
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it) {
@@ -133,6 +164,7 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
         }
     }
     __syncthreads();
+    K1_STAMP(3)
     float *Gs = U;           // [R][R]
     float *Sm = U + R * R;   // [S][V][V]
     for (int sl = 0; sl < TS; ++sl) {  // sum the TS partial Grams, one slice at a time
@@ -153,6 +185,7 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
         }
         __syncthreads();
     }
+    K1_STAMP(4)
     const float denom = (float)(inter_c * T);  // A1.size(-1) at unit_agcn.py:84
     for (int e = tid; e < S * V * V; e += NTH) {
         const int s = e / (V * V), vw = e - s * V * V;
@@ -169,7 +202,9 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
         Sm[e] = sacc / denom;
     }
     __syncthreads();
+    K1_STAMP(5)
     softmax_columns_store(Sm, A_eff, P + (size_t)n * S * V * V, S, V, 0, tid, NTH);
+    K1_STAMP(6)
 
     // Optional feature pass for the fused stem (Cin = 3, S = 3 only): per pixel (t,w) the 12 graph-conv
     // features [u_0, u_1, u_2, x] with u_s[k] = sum_v x[k,t,v] P_s[v,w]  (model/unit_agcn.py:87-88), then a
@@ -177,38 +212,55 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     if (feat == nullptr) return;
     float *Xf = U;  // [3][tcf*V], reuses the dead Gram region
     const int TCF = (R * R) / (3 * V);
+    // Each lane builds one 64-byte feature row; storing it directly is 16 B per lane at a 64-B stride (store-issue
+    // bound, measured ~4 B/clk/CU).  Instead the wave parks its 64 rows (4 KiB) in a private LDS slice and writes
+    // them back out lane-linear: four fully coalesced 1-KiB stores.
+    float4 *slice = reinterpret_cast<float4 *>(smem + feat_slice_off) + (tid >> 6) * 256;
+    const int lane = tid & 63;
     float4 *fo = reinterpret_cast<float4 *>(feat) + (size_t)n * T * V * 4;
     for (int t0 = 0; t0 < T; t0 += TCF) {
         const int tcf = min(TCF, T - t0);
         const int px = tcf * V;
         __syncthreads();  // P complete in Sm / previous chunk consumed
-        for (int e = tid; e < 3 * px; e += NTH) {
-            const int k = e / px, p = e - k * px;
-            Xf[e] = xn[((size_t)k * T + t0) * V + p];
+        for (int k = 0; k < 3; ++k) {
+            const float *xk = xn + ((size_t)k * T + t0) * V;
+            for (int e = tid; e < px; e += NTH) Xf[k * px + e] = xk[e];
         }
         __syncthreads();
-        for (int p = tid; p < px; p += NTH) {
-            const int tt = p / V, w = p - tt * V;
-            float u[9];
+        for (int p0 = (tid & ~63); p0 < px; p0 += NTH) {   // 64 consecutive pixels per wave
+            const int p = p0 + lane;
+            if (p < px) {
+                const int tt = p / V, w = p - tt * V;
+                float u[9];
 #pragma unroll
-            for (int f = 0; f < 9; ++f) u[f] = 0.f;
-            for (int v = 0; v < V; ++v) {
-                const float x0 = Xf[tt * V + v], x1 = Xf[px + tt * V + v], x2 = Xf[2 * px + tt * V + v];
+                for (int f = 0; f < 9; ++f) u[f] = 0.f;
+#pragma unroll 2
+                for (int v = 0; v < V; ++v) {
+                    const float x0 = Xf[tt * V + v], x1 = Xf[px + tt * V + v], x2 = Xf[2 * px + tt * V + v];
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) {
-                    const float pw = Sm[(s3 * V + v) * V + w];
-                    u[s3 * 3 + 0] = fmaf(x0, pw, u[s3 * 3 + 0]);
-                    u[s3 * 3 + 1] = fmaf(x1, pw, u[s3 * 3 + 1]);
-                    u[s3 * 3 + 2] = fmaf(x2, pw, u[s3 * 3 + 2]);
+                    for (int s3 = 0; s3 < 3; ++s3) {
+                        const float pw = Sm[(s3 * V + v) * V + w];
+                        u[s3 * 3 + 0] = fmaf(x0, pw, u[s3 * 3 + 0]);
+                        u[s3 * 3 + 1] = fmaf(x1, pw, u[s3 * 3 + 1]);
+                        u[s3 * 3 + 2] = fmaf(x2, pw, u[s3 * 3 + 2]);
+                    }
                 }
+                slice[lane * 4 + 0] = make_float4(u[0], u[1], u[2], u[3]);
+                slice[lane * 4 + 1] = make_float4(u[4], u[5], u[6], u[7]);
+                slice[lane * 4 + 2] = make_float4(u[8], Xf[p], Xf[px + p], Xf[2 * px + p]);
+                slice[lane * 4 + 3] = make_float4(1.f, 0.f, 0.f, 0.f);
             }
-            float4 *dst = fo + ((size_t)t0 * V + p) * 4;
-            dst[0] = make_float4(u[0], u[1], u[2], u[3]);
-            dst[1] = make_float4(u[4], u[5], u[6], u[7]);
-            dst[2] = make_float4(u[8], Xf[p], Xf[px + p], Xf[2 * px + p]);
-            dst[3] = make_float4(1.f, 0.f, 0.f, 0.f);
+            // wave-private: same wave reads what it wrote (the compiler's lgkmcnt wait orders it)
+            const int nrow = min(64, px - p0);
+            float4 *dst = fo + ((size_t)t0 * V + p0) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = j * 64 + lane;
+                if (idx < nrow * 4) dst[idx] = slice[idx];
+            }
         }
     }
+    K1_STAMP(7)
 }
 
 // Generic Cin: one workgroup per (subset, clip).
@@ -283,12 +335,48 @@ __global__ __launch_bounds__(256) void attention_generic_kernel(
 }  // namespace
 
 // true when launch_attention can also emit the (N, T*V, 16) feature tensor (folded kernel, Cin = 3, S = 3)
-bool attention_emits_features(int Cin, int V, int S) {
-    if (Cin != 3 || S != 3) return false;
+// launch geometry of the folded kernel (shared by the capability query and the launcher)
+struct FoldedPlan {
+    bool ok = false;
+    int maxit = 0, ts = 0, TC = 0, Rp = 0, slice_off = 0;
+    size_t lds = 0;
+};
+
+static FoldedPlan plan_folded(int Cin, int T, int V, int inter_c, int S, bool with_features) {
+    FoldedPlan pl;
     const int C1 = Cin + 1, R = Cin * V + 1;
-    const int ntiles = ceil_div(R, TM) * ceil_div(R, TN);
+    const int nTr = ceil_div(R, TM), nTc = ceil_div(R, TN);
+    const int ntiles = nTr * nTc;
     const size_t gs_floats = (size_t)R * R + (size_t)S * V * V;
-    return S * C1 * C1 <= MS_FLOATS && ntiles <= 8 * 256 && (MS_FLOATS + gs_floats) * 4 <= 150 * 1024;
+    if (Cin > 4 || S * C1 * C1 > MS_FLOATS || ntiles > 8 * 256) return pl;
+    if (with_features && (Cin != 3 || S != 3)) return pl;
+    pl.maxit = ceil_div(ntiles, 256);
+    pl.ts = pl.maxit <= 4 ? 4 : 2;                           // time slices: 1024 or 512 threads
+    pl.Rp = (nTr * TM > nTc * TN ? nTr * TM : nTc * TN) | 1; // odd row stride spreads the tile reads over banks
+    const size_t slices = with_features ? (size_t)4 * pl.ts * 4096 : 0;   // 4 KiB per wave for the coalesced feature rows
+    // chunk of frames held in LDS: the whole clip when it fits in ~96 KiB, else as many frames as do
+    size_t budget = (size_t)96 * 1024 / 4;
+    if (gs_floats > budget) budget = gs_floats;
+    if ((MS_FLOATS + budget) * 4 + slices > (size_t)kLdsBytes) budget = ((size_t)kLdsBytes - slices) / 4 - MS_FLOATS;
+    if (budget < gs_floats) return pl;                       // Gram + attention matrices must fit
+    int TC = (int)(budget / pl.Rp);
+    if (TC > T) TC = T;
+    if (TC < 1) return pl;
+    size_t u_floats = (size_t)TC * pl.Rp;
+    if (u_floats < gs_floats) u_floats = gs_floats;
+    const size_t wl_floats = (size_t)2 * S * inter_c * C1;   // LDS copy of the embedding weights
+    if (u_floats < wl_floats) u_floats = wl_floats;
+    u_floats = (u_floats + 3) / 4 * 4;                       // keep the feature slices 16-B aligned
+    pl.TC = TC;
+    pl.slice_off = (int)(MS_FLOATS + u_floats);              // in floats
+    pl.lds = (MS_FLOATS + u_floats) * 4 + slices;
+    pl.ok = pl.lds <= (size_t)kLdsBytes;
+    return pl;
+}
+
+// true when launch_attention can also emit the (N, T*V, 16) feature tensor (folded kernel, Cin = 3, S = 3)
+bool attention_emits_features(int Cin, int V, int S) {
+    return plan_folded(Cin, 1 << 20, V, 32, S, true).ok;
 }
 
 int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
@@ -296,43 +384,27 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
                      int inter_c, int S, hipStream_t st) {
     if (feat != nullptr && (Cin != 3 || S != 3))
         return fail(STGCN_ERR_UNSUPPORTED, "attention: the feature pass covers Cin=3, 3 subsets (got %d, %d)", Cin, S);
-    const int C1 = Cin + 1;
-    const int R = Cin * V + 1;
-    const int nTr = ceil_div(R, TM), nTc = ceil_div(R, TN);
-    const int ntiles = nTr * nTc;
-    const size_t gs_floats = (size_t)R * R + (size_t)S * V * V;
-    const bool folded = Cin <= 4 && S * C1 * C1 <= MS_FLOATS && ntiles <= 8 * 256 &&
-                        (MS_FLOATS + gs_floats) * 4 <= 150 * 1024;
-    if (folded) {
-        int Rp = nTr * TM > nTc * TN ? nTr * TM : nTc * TN;
-        Rp |= 1;  // odd row stride spreads the per-thread tile reads over banks
-        // chunk of frames held in LDS: whole clip when it fits in ~64 KiB, else as many as do
-        size_t budget = (size_t)96 * 1024 / 4;
-        if (gs_floats > budget) budget = gs_floats;
-        int TC = (int)(budget / Rp);
-        if (TC > T) TC = T;
-        if (TC < 1) TC = 1;
-        size_t u_floats = (size_t)TC * Rp;
-        if (u_floats < gs_floats) u_floats = gs_floats;
-        const size_t lds = (MS_FLOATS + u_floats) * 4;
-        const int maxit = ceil_div(ntiles, 256);
+    const FoldedPlan pl = plan_folded(Cin, T, V, inter_c, S, feat != nullptr);
+    if (feat != nullptr && !pl.ok)
+        return fail(STGCN_ERR_UNSUPPORTED, "attention: V=%d too large for the feature pass", V);
+    if (pl.ok) {
+        const int TC = pl.TC, Rp = pl.Rp, slice_off = pl.slice_off;
+        const size_t lds = pl.lds;
 #define LAUNCH_FOLDED(MI, TSL)                                                                          \
     do {                                                                                               \
         STGCN_HIP_CHECK(allow_lds((attention_folded_kernel<MI, TSL>), lds));                           \
         hipLaunchKernelGGL((attention_folded_kernel<MI, TSL>), dim3(N), dim3(256 * TSL), lds, st, x, A_eff, \
-                           Wa, ba, Wb, bb, P, feat, Cin, T, V, inter_c, S, TC, Rp);                    \
+                           Wa, ba, Wb, bb, P, feat, Cin, T, V, inter_c, S, TC, Rp, slice_off, debug_buffer()); \
     } while (0)
-        if (maxit <= 1) LAUNCH_FOLDED(1, 4);
-        else if (maxit <= 2) LAUNCH_FOLDED(2, 4);
-        else if (maxit <= 4) LAUNCH_FOLDED(4, 4);
+        if (pl.maxit <= 1) LAUNCH_FOLDED(1, 4);
+        else if (pl.maxit <= 2) LAUNCH_FOLDED(2, 4);
+        else if (pl.maxit <= 4) LAUNCH_FOLDED(4, 4);
         else LAUNCH_FOLDED(8, 2);
 #undef LAUNCH_FOLDED
         STGCN_LAUNCH_CHECK("attention_folded_kernel");
         return STGCN_OK;
     }
     // generic path
-    if (feat != nullptr)
-        return fail(STGCN_ERR_UNSUPPORTED, "attention: V=%d too large for the feature pass", V);
     const int maxit = ceil_div(V * V, 256);
     if (maxit > 16) return fail(STGCN_ERR_UNSUPPORTED, "attention: V=%d too large (max 64)", V);
     const size_t budget = (size_t)96 * 1024 / 4;

@@ -54,6 +54,7 @@ typedef enum {
 
 #define STGCN_MATH_MASK 0xFu
 #define STGCN_OUT_BF16 0x10u
+#define STGCN_RAW 0x20u /* stgcn_tcn_*: store scale-folded conv + shift WITHOUT the ReLU (pre-activation) */
 
 int stgcn_version(void);
 const char *stgcn_last_error(void);
@@ -146,6 +147,31 @@ int stgcn_stem_forward_prepared(const float *x, const float *A_eff, const float 
                                 const void *prep, const float *t_shift, void *ws, size_t ws_bytes,
                                 void *out, int N, int Cin, int C, int T, int V, int inter_c,
                                 int subsets, int K, unsigned flags, void *stream);
+
+/* ---- training-mode forward (batch-statistics BatchNorm) ------------------------------------------
+ * Same math as the eval entry points, but every BatchNorm2d normalises with the statistics of the
+ * batch over (N,T,V) and updates its running buffers in place exactly like torch (momentum, unbiased
+ * variance); num_batches_tracked is the caller's to increment.  bn_* / dbn_* are the raw BatchNorm
+ * tensors (weight, bias, running_mean, running_var), not folded scale/shift.  `ws` is caller workspace
+ * of stgcn_*_train_ws_bytes bytes.  Forward only: no gradients are produced.
+ *   stgcn_agcn_forward_train <- model/unit_agcn.py:73-93 with self.training (P_ws, y as in stgcn_agcn_forward)
+ *   stgcn_tcn_forward_train  <- model/net.py:47-57 with self.training (dropout p = 0)
+ */
+size_t stgcn_agcn_train_ws_bytes(int N, int Cout, int T, int V);
+int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa, const float *ba,
+                             const float *Wb, const float *bb, const float *Wd, const float *bd,
+                             const float *Wdown, const float *bdown, const float *bn_weight,
+                             const float *bn_bias, float *bn_running_mean, float *bn_running_var,
+                             const float *dbn_weight, const float *dbn_bias, float *dbn_running_mean,
+                             float *dbn_running_var, float momentum, float eps, float *P_ws, void *ws,
+                             size_t ws_bytes, float *y, int N, int Cin, int Cout, int T, int V,
+                             int inter_c, int subsets, void *stream);
+size_t stgcn_tcn_train_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
+int stgcn_tcn_forward_train(const float *x, const float *W, const float *conv_bias,
+                            const float *bn_weight, const float *bn_bias, float *bn_running_mean,
+                            float *bn_running_var, float momentum, float eps, void *ws, size_t ws_bytes,
+                            float *y, int N, int Cin, int Cout, int T, int V, int K, int stride,
+                            unsigned flags, void *stream);
 
 /* ---- data-parallel harness -------------------------------------------------------------------
  * Per-rank reductions that the ranks all-reduce once per step (the data-parallel form of the

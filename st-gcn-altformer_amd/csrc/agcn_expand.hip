@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void agcn_expand_small_kernel(
     const float *__restrict__ bd, const float *__restrict__ Wdown, const float *__restrict__ bdown,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
     const float *__restrict__ down_scale, const float *__restrict__ down_shift,
-    float *__restrict__ y, int Cout, int T, int V, int TF) {
+    float *__restrict__ y, int Cout, int T, int V, int TF, int mode) {
     constexpr int F = (S + 1) * CIN;
     constexpr int FP = (F + 1 + 3) / 4 * 4;  // row of folded weights: F weights, bias, pad to x4
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void agcn_expand_small_kernel(
             float acc = wr[F];
 #pragma unroll
             for (int f = 0; f < F; ++f) acc = fmaf(wr[f], feat[f], acc);
-            yo[(size_t)o * T * V] = fmaxf(acc, 0.f);
+            yo[(size_t)o * T * V] = (mode & 1) ? acc : fmaxf(acc, 0.f);  // mode bit 0: raw (pre-activation) output
         }
     }
 }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void agcn_expand_generic_kernel(
     const float *__restrict__ bd, const float *__restrict__ Wdown, const float *__restrict__ bdown,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
     const float *__restrict__ down_scale, const float *__restrict__ down_shift,
-    float *__restrict__ y, int Cin, int Cout, int T, int V, int S, int TF) {
+    float *__restrict__ y, int Cin, int Cout, int T, int V, int S, int TF, int mode) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
@@ -152,9 +152,9 @@ __global__ __launch_bounds__(256) void agcn_expand_generic_kernel(
                     float b = 0.f;
                     for (int s = 0; s < S; ++s) b += bd[s * Cout + o];
                     float val = fmaf(bn_scale[o], acc[j] + b, bn_shift[o]);
-                    if (identity) val += Xs[o * PXM + p];
+                    if (identity) { if (!(mode & 2)) val += Xs[o * PXM + p]; }  // mode bit 1: leave the residual out
                     else val += fmaf(down_scale[o], res[j] + bdown[o], down_shift[o]);
-                    yo[(size_t)o * T * V] = fmaxf(val, 0.f);
+                    yo[(size_t)o * T * V] = (mode & 1) ? val : fmaxf(val, 0.f);
                 }
             }
         }
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void agcn_expand_generic_kernel(
 int launch_agcn_expand(const float *x, const float *P, const float *Wd, const float *bd,
                        const float *Wdown, const float *bdown, const float *bn_scale,
                        const float *bn_shift, const float *down_scale, const float *down_shift,
-                       float *y, int N, int Cin, int Cout, int T, int V, int S, hipStream_t st) {
+                       float *y, int N, int Cin, int Cout, int T, int V, int S, int mode, hipStream_t st) {
     if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "agcn: N=%d > 65535 clips per call", N);
     if (Cin == 3 && S == 3 && Wdown != nullptr && V <= 256) {
         constexpr int F = 12, FP = 16;
@@ -179,7 +179,7 @@ int launch_agcn_expand(const float *x, const float *P, const float *Wd, const fl
             STGCN_HIP_CHECK(allow_lds(agcn_expand_small_kernel<3, 3>, lds));
             hipLaunchKernelGGL((agcn_expand_small_kernel<3, 3>), dim3(ceil_div(T, TF), N), dim3(256), lds,
                                st, x, P, Wd, bd, Wdown, bdown, bn_scale, bn_shift, down_scale, down_shift,
-                               y, Cout, T, V, TF);
+                               y, Cout, T, V, TF, mode);
             STGCN_LAUNCH_CHECK("agcn_expand_small_kernel");
             return STGCN_OK;
         }
@@ -198,7 +198,7 @@ int launch_agcn_expand(const float *x, const float *P, const float *Wd, const fl
     STGCN_HIP_CHECK(allow_lds(agcn_expand_generic_kernel, lds));
     hipLaunchKernelGGL(agcn_expand_generic_kernel, dim3(ceil_div(T, TF), N), dim3(256), lds, st, x, P, Wd,
                        bd, Wdown, bdown, bn_scale, bn_shift, down_scale, down_shift, y, Cin, Cout, T, V, S,
-                       TF);
+                       TF, mode);
     STGCN_LAUNCH_CHECK("agcn_expand_generic_kernel");
     return STGCN_OK;
 }

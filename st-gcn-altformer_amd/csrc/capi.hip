@@ -133,7 +133,7 @@ int stgcn_agcn_forward(const float *x, const float *A_eff, const float *Wa, cons
     int rc = stgcn_agcn_attention(x, A_eff, Wa, ba, Wb, bb, P_ws, N, Cin, T, V, inter_c, subsets, stream);
     if (rc != STGCN_OK) return rc;
     return launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, bn_scale, bn_shift, down_scale, down_shift, y, N,
-                              Cin, Cout, T, V, subsets, (hipStream_t)stream);
+                              Cin, Cout, T, V, subsets, 0, (hipStream_t)stream);
 }
 
 size_t stgcn_tcn_packed_bytes(int Cin, int Cout, int K, unsigned flags) {
@@ -241,6 +241,110 @@ int stgcn_stem_forward_prepared(const float *x, const float *A_eff, const float 
                                   stream);
     if (rc != STGCN_OK) return rc;
     return stgcn_stem_tail_prepared(x, ws, ws_bytes, prep, t_shift, out, N, Cin, C, T, V, subsets, K, flags, stream);
+}
+
+// ---- training-mode forward ------------------------------------------------------------------------------------
+// workspace layout (agcn): [ones C][zeros C][scale/shift 4*C floats][sums 2 x 2C doubles][z_main N*C*T*V][z_down N*C*T*V]
+static size_t train_small_bytes(int C) { return align_up((size_t)C * 6 * sizeof(float) + (size_t)C * 4 * sizeof(double), 256); }
+
+size_t stgcn_agcn_train_ws_bytes(int N, int Cout, int T, int V) {
+    if (N <= 0 || Cout <= 0 || T <= 0 || V <= 0) return 0;
+    return train_small_bytes(Cout) + (size_t)2 * N * Cout * T * V * sizeof(float);
+}
+
+__global__ static void fill_ones_zeros_kernel(float *ones, float *zeros, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) { ones[c] = 1.f; zeros[c] = 0.f; }
+}
+
+int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa, const float *ba, const float *Wb,
+                             const float *bb, const float *Wd, const float *bd, const float *Wdown,
+                             const float *bdown, const float *bn_weight, const float *bn_bias, float *bn_running_mean,
+                             float *bn_running_var, const float *dbn_weight, const float *dbn_bias,
+                             float *dbn_running_mean, float *dbn_running_var, float momentum, float eps, float *P_ws,
+                             void *ws, size_t ws_bytes, float *y, int N, int Cin, int Cout, int T, int V, int inter_c,
+                             int subsets, void *stream) {
+    REQUIRE_PTR(Wd); REQUIRE_PTR(bd); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias); REQUIRE_PTR(bn_running_mean);
+    REQUIRE_PTR(bn_running_var); REQUIRE_PTR(ws); REQUIRE_PTR(y); REQUIRE_POS(Cout);
+    const bool has_down = Wdown != nullptr;
+    if (has_down && (!bdown || !dbn_weight || !dbn_bias || !dbn_running_mean || !dbn_running_var))
+        return fail(STGCN_ERR_ARG, "agcn_forward_train: down branch given without its bias / BatchNorm tensors");
+    if (!has_down && Cin != Cout)
+        return fail(STGCN_ERR_ARG, "agcn_forward_train: identity residual needs Cin == Cout (got %d, %d)", Cin, Cout);
+    int rc = stgcn_agcn_attention(x, A_eff, Wa, ba, Wb, bb, P_ws, N, Cin, T, V, inter_c, subsets, stream);
+    if (rc != STGCN_OK) return rc;
+    if (ws_bytes < stgcn_agcn_train_ws_bytes(N, Cout, T, V))
+        return fail(STGCN_ERR_WORKSPACE, "agcn_forward_train: workspace %zu B too small", ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    float *ones = (float *)ws, *zeros = ones + Cout, *s1 = zeros + Cout, *t1 = s1 + Cout, *s2 = t1 + Cout, *t2 = s2 + Cout;
+    double *sums1 = (double *)(t2 + Cout), *sums2 = sums1 + 2 * Cout;
+    float *zm = (float *)((char *)ws + train_small_bytes(Cout));
+    float *zd = zm + (size_t)N * Cout * T * V;
+    const size_t plane = (size_t)T * V, total = (size_t)N * Cout * plane;
+    hipLaunchKernelGGL(fill_ones_zeros_kernel, dim3(ceil_div(Cout, 256)), dim3(256), 0, st, ones, zeros, Cout);
+    STGCN_LAUNCH_CHECK("fill_ones_zeros_kernel");
+    // main branch, pre-BN: sum_s conv_d_s(x P_s)   (unit scale on the main path, zero on the residual path, no ReLU)
+    rc = launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, ones, zeros, has_down ? zeros : nullptr,
+                            has_down ? zeros : nullptr, zm, N, Cin, Cout, T, V, subsets, 1 | 2, st);
+    if (rc != STGCN_OK) return rc;
+    rc = launch_bn_batch_stats(zm, sums1, N, Cout, plane, st);
+    if (rc != STGCN_OK) return rc;
+    rc = launch_bn_train_finalize(sums1, (double)N * plane, bn_weight, bn_bias, bn_running_mean, bn_running_var, momentum,
+                                  eps, s1, t1, Cout, st);
+    if (rc != STGCN_OK) return rc;
+    if (has_down) {  // residual branch, pre-BN: conv_down(x)
+        rc = launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, zeros, zeros, ones, zeros, zd, N, Cin, Cout, T, V, subsets,
+                                1, st);
+        if (rc != STGCN_OK) return rc;
+        rc = launch_bn_batch_stats(zd, sums2, N, Cout, plane, st);
+        if (rc != STGCN_OK) return rc;
+        rc = launch_bn_train_finalize(sums2, (double)N * plane, dbn_weight, dbn_bias, dbn_running_mean, dbn_running_var,
+                                      momentum, eps, s2, t2, Cout, st);
+        if (rc != STGCN_OK) return rc;
+        return launch_bn_apply(zm, s1, t1, zd, s2, t2, y, total, Cout, plane, st);
+    }
+    return launch_bn_apply(zm, s1, t1, x, nullptr, nullptr, y, total, Cout, plane, st);  // identity residual: + x
+}
+
+// workspace layout (tcn): [ones C][zeros C][scale, shift][sums 2C doubles][packed weights][z N*Cout*Tout*V]
+size_t stgcn_tcn_train_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || K <= 0 || stride <= 0) return 0;
+    const int Tout = (T + 2 * ((K - 1) / 2) - K) / stride + 1;
+    if (Tout < 1) return 0;
+    return train_small_bytes(Cout) + tcn_packed_bytes(Cin, Cout, K, flags) + (size_t)N * Cout * Tout * V * sizeof(float);
+}
+
+int stgcn_tcn_forward_train(const float *x, const float *W, const float *conv_bias, const float *bn_weight,
+                            const float *bn_bias, float *bn_running_mean, float *bn_running_var, float momentum,
+                            float eps, void *ws, size_t ws_bytes, float *y, int N, int Cin, int Cout, int T, int V,
+                            int K, int stride, unsigned flags, void *stream) {
+    REQUIRE_PTR(x); REQUIRE_PTR(W); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias); REQUIRE_PTR(bn_running_mean);
+    REQUIRE_PTR(bn_running_var); REQUIRE_PTR(ws); REQUIRE_PTR(y);
+    REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(Cout); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(K); REQUIRE_POS(stride);
+    const size_t need = stgcn_tcn_train_ws_bytes(N, Cin, Cout, T, V, K, stride, flags);
+    if (need == 0) return fail(STGCN_ERR_ARG, "tcn_forward_train: T=%d K=%d stride=%d gives no output frame", T, K, stride);
+    if (ws_bytes < need) return fail(STGCN_ERR_WORKSPACE, "tcn_forward_train: workspace %zu B < %zu B", ws_bytes, need);
+    if (flags & STGCN_OUT_BF16) return fail(STGCN_ERR_UNSUPPORTED, "tcn_forward_train: fp32 output only");
+    hipStream_t st = (hipStream_t)stream;
+    const int Tout = (T + 2 * ((K - 1) / 2) - K) / stride + 1;
+    float *ones = (float *)ws, *zeros = ones + Cout, *s1 = zeros + Cout, *t1 = s1 + Cout;
+    double *sums = (double *)(t1 + 3 * Cout);
+    char *packed = (char *)ws + train_small_bytes(Cout);
+    float *z = (float *)(packed + tcn_packed_bytes(Cin, Cout, K, flags));
+    const size_t plane = (size_t)Tout * V, total = (size_t)N * Cout * plane;
+    hipLaunchKernelGGL(fill_ones_zeros_kernel, dim3(ceil_div(Cout, 256)), dim3(256), 0, st, ones, zeros, Cout);
+    STGCN_LAUNCH_CHECK("fill_ones_zeros_kernel");
+    int rc = launch_tcn_pack(W, ones, packed, Cin, Cout, K, flags, st);   // unit scale: the raw convolution
+    if (rc != STGCN_OK) return rc;
+    rc = launch_tcn(x, packed, conv_bias ? conv_bias : zeros, z, N, Cin, Cout, T, V, K, stride,
+                    (flags & STGCN_MATH_MASK) | STGCN_RAW, st);
+    if (rc != STGCN_OK) return rc;
+    rc = launch_bn_batch_stats(z, sums, N, Cout, plane, st);
+    if (rc != STGCN_OK) return rc;
+    rc = launch_bn_train_finalize(sums, (double)N * plane, bn_weight, bn_bias, bn_running_mean, bn_running_var, momentum,
+                                  eps, s1, t1, Cout, st);
+    if (rc != STGCN_OK) return rc;
+    return launch_bn_apply(z, s1, t1, nullptr, nullptr, nullptr, y, total, Cout, plane, st);
 }
 
 int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int C, long plane, float n_local,

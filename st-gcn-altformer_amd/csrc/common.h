@@ -75,7 +75,7 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
 int launch_agcn_expand(const float *x, const float *P, const float *Wd, const float *bd,
                        const float *Wdown, const float *bdown, const float *bn_scale,
                        const float *bn_shift, const float *down_scale, const float *down_shift,
-                       float *y, int N, int Cin, int Cout, int T, int V, int S, hipStream_t st);
+                       float *y, int N, int Cin, int Cout, int T, int V, int S, int mode, hipStream_t st);
 
 // temporal conv
 size_t tcn_packed_bytes(int Cin, int Cout, int K, unsigned flags);
@@ -100,6 +100,14 @@ bool attention_emits_features(int Cin, int V, int S);
 bool stem_v4_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags);
 int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, const float *shift, void *out, int N,
                    int C, int T, int V, int K, unsigned flags, hipStream_t st);
+
+// training-mode BatchNorm helpers (train_bn.hip)
+int launch_bn_batch_stats(const float *z, double *sums, int N, int C, size_t plane, hipStream_t st);
+int launch_bn_train_finalize(const double *sums, double count, const float *weight, const float *bias,
+                             float *running_mean, float *running_var, float momentum, float eps, float *scale,
+                             float *shift, int C, hipStream_t st);
+int launch_bn_apply(const float *za, const float *sa, const float *ta, const float *zb, const float *sb,
+                    const float *tb, float *y, size_t total, int C, size_t plane, hipStream_t st);
 
 // fused stem
 size_t stem_prep_bytes(int Cin, int C, int K, int S, unsigned flags);

@@ -70,7 +70,7 @@ template <int JPR, int TERMS, bool BF16OUT, bool FUSED, int KT>
 __global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
     const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ W12,
     const uint4 *__restrict__ Wp, const float *__restrict__ shift, void *y, int Cin, int Cout, int T, int V,
-    int Krt, int stride, int Tout, int ROWS /* pixel rows per image */, int abl) {
+    int Krt, int stride, int Tout, int ROWS /* pixel rows per image */, int abl, float lo) {
     constexpr int CIN0 = 3, S = 3, F = 12;
     const int K = KT ? KT : Krt;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
-                if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[m][j][r] + sh, 0.f));
+                if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[m][j][r] + sh, lo));
             }
         }
     }
@@ -640,18 +640,18 @@ inline bool plan_bf16(int Cin, int Cout, int V, int K, int stride, int Tout, int
 template <int JPR, int TERMS, bool FUSED, int KT>
 int launch_variant(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y,
                    int N, int Cin, int Cout, int T, int V, int K, int stride, int Tout, const Bf16Plan &pl,
-                   bool bf16out, hipStream_t st) {
+                   bool bf16out, float lo, hipStream_t st) {
     const dim3 grid(ceil_div(Tout * V, NPB), Cout / 128, N);
     if (bf16out) {
         auto kern = tcn_mfma_bf16_kernel<JPR, TERMS, true, FUSED, KT>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, Cin, Cout, T, V, K, stride, Tout,
-                           pl.rows, ablate_mask());
+                           pl.rows, ablate_mask(), lo);
     } else {
         auto kern = tcn_mfma_bf16_kernel<JPR, TERMS, false, FUSED, KT>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, Cin, Cout, T, V, K, stride, Tout,
-                           pl.rows, ablate_mask());
+                           pl.rows, ablate_mask(), lo);
     }
     STGCN_LAUNCH_CHECK("tcn_mfma_bf16_kernel");
     return STGCN_OK;
@@ -660,10 +660,10 @@ int launch_variant(const float *x, const float *P, const float *W12, const uint4
 template <int TERMS, bool FUSED>
 int dispatch_tcn(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y, int N,
              int Cin, int Cout, int T, int V, int K, int stride, int Tout, const Bf16Plan &pl, bool bf16out,
-             hipStream_t st) {
+             float lo, hipStream_t st) {
 #define GO(JPR, KT)                                                                                             \
     return launch_variant<JPR, TERMS, FUSED, KT>(x, P, W12, Wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, \
-                                                 bf16out, st)
+                                                 bf16out, lo, st)
     if (K == 9) {
         if (pl.jpr == 1) GO(1, 9);
         if (pl.jpr == 2) GO(2, 9);
@@ -723,8 +723,9 @@ int launch_tcn_bf16(const float *x, const float *P, const float *W12, const void
                     "bf16 MFMA kernel does not cover Cin=%d Cout=%d V=%d K=%d stride=%d T=%d (needs Cin%%16==0, "
                     "Cout%%128==0, tile rows that fit LDS)", Cin, Cout, V, K, stride, T);
     const uint4 *wp = (const uint4 *)Wp;
-    if (terms == 3) return dispatch_tcn<3, false>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, st);
-    return dispatch_tcn<1, false>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, st);
+    const float lo = (flags & STGCN_RAW) ? -__builtin_huge_valf() : 0.f;  // raw = pre-activation (training-mode BN)
+    if (terms == 3) return dispatch_tcn<3, false>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, lo, st);
+    return dispatch_tcn<1, false>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, lo, st);
 }
 
 }  // namespace stgcn

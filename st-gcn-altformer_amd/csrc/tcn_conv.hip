@@ -60,7 +60,8 @@ template <bool BF16OUT>
 __global__ __launch_bounds__(256) void tcn_valu_kernel(const float *__restrict__ x,
                                                        const float *__restrict__ Wp,
                                                        const float *__restrict__ shift, void *y, int Cin,
-                                                       int Cout, int T, int V, int K, int stride, int Tout) {
+                                                       int Cout, int T, int V, int K, int stride, int Tout,
+                                                       float lo /* 0: ReLU, -inf: raw pre-activation */) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int o0 = blockIdx.y * OBV;
     const int n = blockIdx.z;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void tcn_valu_kernel(const float *__restrict__
 #pragma unroll
     for (int j = 0; j < OBV; ++j)
         if (o0 + j < Cout)
-            store_out<BF16OUT>(y, ((size_t)n * Cout + o0 + j) * Tout * V + q, fmaxf(acc[j] + shift[o0 + j], 0.f));
+            store_out<BF16OUT>(y, ((size_t)n * Cout + o0 + j) * Tout * V + q, fmaxf(acc[j] + shift[o0 + j], lo));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -198,7 +199,7 @@ __device__ __forceinline__ void mfma_tap(f32x16 (&acc)[4], float4 a0, float4 a1,
 template <bool BF16OUT>
 __device__ __forceinline__ void epilogue_store(const f32x16 (&acc)[4], const TileGeom &g,
                                                const float *__restrict__ shift, void *y, int n, int Cout,
-                                               int mb, int lane, int pixels_per_clip) {
+                                               int mb, int lane, int pixels_per_clip, float lo = 0.f) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int o = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -207,7 +208,7 @@ __device__ __forceinline__ void epilogue_store(const f32x16 (&acc)[4], const Til
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int q = g.q0 + j * 32 + (lane & 31);
-            if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[j][r] + sh, 0.f));
+            if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[j][r] + sh, lo));
         }
     }
 }
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void tcn_mfma_f32_kernel(const float *__restri
                                                            const float4 *__restrict__ Wp,
                                                            const float *__restrict__ shift, void *y,
                                                            int Cin, int Cout, int T, int V, int K,
-                                                           int stride, int Tout, int ROW) {
+                                                           int stride, int Tout, int ROW, float lo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void tcn_mfma_f32_kernel(const float *__restri
         if (more) commit(nxt);
         __syncthreads();
     }
-    epilogue_store<BF16OUT>(acc, g, shift, y, n, Cout, mb, lane, Tout * V);
+    epilogue_store<BF16OUT>(acc, g, shift, y, n, Cout, mb, lane, Tout * V, lo);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -502,6 +503,7 @@ int launch_tcn(const float *x, const void *Wp, const float *shift, void *y, int 
                int T, int V, int K, int stride, unsigned flags, hipStream_t st) {
     const unsigned math = flags & STGCN_MATH_MASK;
     const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
+    const float lo = (flags & STGCN_RAW) ? -__builtin_huge_valf() : 0.f;  // raw = pre-activation (training-mode BN)
     const int pad = (K - 1) / 2;
     const int Tout = (T + 2 * pad - K) / stride + 1;
     if (Tout < 1) return fail(STGCN_ERR_ARG, "tcn: T=%d K=%d stride=%d gives no output frame", T, K, stride);
@@ -524,7 +526,7 @@ int launch_tcn(const float *x, const void *Wp, const float *shift, void *y, int 
     do {                                                                                            \
         STGCN_HIP_CHECK(allow_lds(tcn_mfma_f32_kernel<J, B>, lds));                                 \
         hipLaunchKernelGGL((tcn_mfma_f32_kernel<J, B>), grid, dim3(256), lds, st, x, (const float4 *)Wp, \
-                           shift, y, Cin, Cout, T, V, K, stride, Tout, ROW);                        \
+                           shift, y, Cin, Cout, T, V, K, stride, Tout, ROW, lo);                    \
     } while (0)
         if (jpr == 1) { if (bf16out) LAUNCH_TCN(1, true); else LAUNCH_TCN(1, false); }
         else if (jpr == 2) { if (bf16out) LAUNCH_TCN(2, true); else LAUNCH_TCN(2, false); }
@@ -536,10 +538,10 @@ int launch_tcn(const float *x, const void *Wp, const float *shift, void *y, int 
     const dim3 grid(ceil_div(Tout * V, 256), ceil_div(Cout, OBV), N);
     if (bf16out)
         hipLaunchKernelGGL((tcn_valu_kernel<true>), grid, dim3(256), 0, st, x, (const float *)Wp, shift, y, Cin,
-                           Cout, T, V, K, stride, Tout);
+                           Cout, T, V, K, stride, Tout, lo);
     else
         hipLaunchKernelGGL((tcn_valu_kernel<false>), grid, dim3(256), 0, st, x, (const float *)Wp, shift, y,
-                           Cin, Cout, T, V, K, stride, Tout);
+                           Cin, Cout, T, V, K, stride, Tout, lo);
     STGCN_LAUNCH_CHECK("tcn_valu_kernel");
     return STGCN_OK;
 }

@@ -1,0 +1,106 @@
+// Training-mode BatchNorm2d pieces (nn.BatchNorm2d at model/unit_agcn.py:54,60 and model/net.py:40 with
+// module.training == True): batch statistics over (N,T,V) per channel, the running-buffer update torch performs
+// (momentum 0.1, unbiased variance), and the elementwise normalise + residual + ReLU.
+//
+// The pre-activation tensors are produced by the same kernels as in eval mode run in "raw" mode (unit scale,
+// zero shift, no ReLU); sums are accumulated in fp64 (one atomicAdd pair per workgroup and channel), so the
+// statistics do not depend on the reduction order beyond fp64 rounding.
+#include "common.h"
+
+namespace stgcn {
+
+namespace {
+
+// sums[c] += sum z[n][c][:],  sums[C + c] += sum z^2     grid = (chunks, C)
+__global__ __launch_bounds__(256) void bn_batch_stats_kernel(const float *__restrict__ z, double *__restrict__ sums,
+                                                              int N, int C, size_t plane) {
+    const int c = blockIdx.y;
+    const size_t per_chunk = (N * plane + gridDim.x - 1) / gridDim.x;
+    const size_t lo = blockIdx.x * per_chunk;
+    const size_t hi = min(lo + per_chunk, (size_t)N * plane);
+    double s1 = 0.0, s2 = 0.0;
+    for (size_t e = lo + threadIdx.x; e < hi; e += 256) {
+        const size_t n = e / plane, p = e - n * plane;
+        const double v = (double)z[(n * C + c) * plane + p];
+        s1 += v;
+        s2 += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o, 64);
+        s2 += __shfl_down(s2, o, 64);
+    }
+    __shared__ double red[2][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&sums[C + c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// batch mean / biased variance -> (scale, shift) of  y = z*scale + shift ; running buffers updated like torch:
+//   running = (1-m)*running + m*batch   with the UNBIASED variance (count/(count-1))
+__global__ void bn_train_finalize_kernel(const double *__restrict__ sums, double count, const float *__restrict__ weight,
+                                         const float *__restrict__ bias, float *__restrict__ running_mean,
+                                         float *__restrict__ running_var, float momentum, float eps,
+                                         float *__restrict__ scale, float *__restrict__ shift, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float s = weight[c] / sqrtf((float)var + eps);
+    scale[c] = s;
+    shift[c] = bias[c] - (float)mean * s;
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+}
+
+// y = relu( za*sa[c] + ta[c] + r ),  r = zb*sb[c] + tb[c]  (sb given), = zb (sb NULL, identity residual), = 0 (zb NULL)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ za, const float *__restrict__ sa,
+                                                        const float *__restrict__ ta, const float *__restrict__ zb,
+                                                        const float *__restrict__ sb, const float *__restrict__ tb,
+                                                        float *__restrict__ y, size_t total, int C, size_t plane) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)((e / plane) % C);
+        float v = fmaf(za[e], sa[c], ta[c]);
+        if (zb != nullptr) v += (sb != nullptr) ? fmaf(zb[e], sb[c], tb[c]) : zb[e];
+        y[e] = fmaxf(v, 0.f);
+    }
+}
+
+}  // namespace
+
+int launch_bn_batch_stats(const float *z, double *sums, int N, int C, size_t plane, hipStream_t st) {
+    STGCN_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
+    const size_t per_c = (size_t)N * plane;
+    int chunks = (int)((per_c + 16383) / 16384);
+    if (chunks > 64) chunks = 64;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(bn_batch_stats_kernel, dim3(chunks, C), dim3(256), 0, st, z, sums, N, C, plane);
+    STGCN_LAUNCH_CHECK("bn_batch_stats_kernel");
+    return STGCN_OK;
+}
+
+int launch_bn_train_finalize(const double *sums, double count, const float *weight, const float *bias,
+                             float *running_mean, float *running_var, float momentum, float eps, float *scale,
+                             float *shift, int C, hipStream_t st) {
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, count, weight, bias,
+                       running_mean, running_var, momentum, eps, scale, shift, C);
+    STGCN_LAUNCH_CHECK("bn_train_finalize_kernel");
+    return STGCN_OK;
+}
+
+int launch_bn_apply(const float *za, const float *sa, const float *ta, const float *zb, const float *sb,
+                    const float *tb, float *y, size_t total, int C, size_t plane, hipStream_t st) {
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, za, sa, ta, zb, sb, tb, y, total, C,
+                       plane);
+    STGCN_LAUNCH_CHECK("bn_apply_kernel");
+    return STGCN_OK;
+}
+
+}  // namespace stgcn

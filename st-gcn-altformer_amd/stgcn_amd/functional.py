@@ -204,6 +204,50 @@ def stem_forward(x, A_eff, Wa, ba, Wb, bb, prep, t_shift, C, K, math=MATH_F32, o
     return out, ws[:N * S * V * V].view(N, S, V, V)
 
 
+def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_bn, momentum=0.1, eps=BN_EPS):
+    """Training-mode forward of unit_agcn (batch-statistics BatchNorm; running buffers of `bn` / `down_bn` are
+    updated in place like torch does).  bn / down_bn: (weight, bias, running_mean, running_var) tensors.
+    Returns (y, P).  Forward only."""
+    dev = x.device
+    N, Cin, T, V = x.shape
+    S, inter_c, _ = Wa.shape
+    Cout = Wd.shape[1]
+    y = torch.empty(N, Cout, T, V, device=dev, dtype=torch.float32)
+    P = torch.empty(N, S, V, V, device=dev, dtype=torch.float32)
+    nbytes = _capi.lib().stgcn_agcn_train_ws_bytes(N, Cout, T, V)
+    ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
+    d = down_bn if down_bn is not None else (None, None, None, None)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_agcn_forward_train", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev),
+                   _dev_ptr(Wa, "Wa", dev), _dev_ptr(ba, "ba", dev), _dev_ptr(Wb, "Wb", dev), _dev_ptr(bb, "bb", dev),
+                   _dev_ptr(Wd, "Wd", dev), _dev_ptr(bd, "bd", dev), _dev_ptr(Wdown, "Wdown", dev),
+                   _dev_ptr(bdown, "bdown", dev), *[_dev_ptr(t, "bn", dev) for t in bn],
+                   *[_dev_ptr(t, "down_bn", dev) for t in d], c_float(momentum), c_float(eps), _dev_ptr(P, "P"),
+                   c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), _dev_ptr(y, "y"), c_int(N), c_int(Cin), c_int(Cout),
+                   c_int(T), c_int(V), c_int(inter_c), c_int(S), _stream(dev))
+    return y, P
+
+
+def tcn_forward_train(x, W, conv_bias, bn, stride=1, math=MATH_F32, momentum=0.1, eps=BN_EPS):
+    """Training-mode forward of Unit2D(dim=2, dropout=0): raw conv -> batch statistics -> normalise -> ReLU."""
+    dev = x.device
+    N, Cin, T, V = x.shape
+    Cout, _, K = W.shape
+    Tout = tcn_out_frames(T, K, stride)
+    if Tout < 1:
+        raise ValueError(f"temporal conv: T={T}, K={K}, stride={stride} leaves no output frame")
+    fl = _flags(math, False)
+    nbytes = _capi.lib().stgcn_tcn_train_ws_bytes(N, Cin, Cout, T, V, K, stride, fl)
+    ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
+    y = torch.empty(N, Cout, Tout, V, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_tcn_forward_train", _dev_ptr(x, "x", dev), _dev_ptr(W, "W", dev),
+                   _dev_ptr(conv_bias, "conv_bias", dev), *[_dev_ptr(t, "bn", dev) for t in bn], c_float(momentum),
+                   c_float(eps), c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), _dev_ptr(y, "y"), c_int(N), c_int(Cin),
+                   c_int(Cout), c_int(T), c_int(V), c_int(K), c_int(stride), c_uint(fl), _stream(dev))
+    return y
+
+
 class KernelTimer:
     """HIP-event bracket around individual kernel launches on the launching stream.
 

@@ -41,11 +41,12 @@ def _versions(mod: nn.Module):
     return tuple(t._version for t in list(mod.parameters()) + list(mod.buffers()))
 
 
-def _require_inference(mod: nn.Module, x: torch.Tensor):
-    if mod.training:
+def _check_input(mod: nn.Module, x: torch.Tensor):
+    if mod.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mod.parameters())):
         raise NotImplementedError(
-            f"{type(mod).__name__}: training-mode forward (batch-statistics BatchNorm + autograd) is not "
-            "implemented by the HIP path yet; call .eval() (SURVEY.md §8f rank 2)")
+            f"{type(mod).__name__}: the HIP path implements the forward only (eval, and training-mode forward with "
+            "batch-statistics BatchNorm under torch.no_grad()); autograd/backward is not implemented "
+            "(SURVEY.md §8f rank 2)")
     if not x.is_cuda:
         raise RuntimeError(
             f"{type(mod).__name__}: input is on {x.device}; the HIP path runs on the GPU only "
@@ -194,13 +195,15 @@ class unit_agcn(nn.Module):
         return F.stem_supported(C, self.out_channels, T, V, t.kernel_size, self.num_subset, t.math_mode)
 
     def forward(self, x):
-        _require_inference(self, x)
+        _check_input(self, x)
         if x.shape[1] != self.in_channels:
             raise RuntimeError(f"unit_agcn: expected {self.in_channels} input channels, got {x.shape[1]}")
         if x.shape[3] != self.PA.shape[-1]:
             raise RuntimeError(f"unit_agcn: input has {x.shape[3]} joints, adjacency has {self.PA.shape[-1]}")
         x = x.contiguous()
         st = self._staged(x.device)
+        if self.training:
+            return self._forward_train(x, st)
         if self._fusable(x):
             t = self._fused_tcn
             ts = t._staged(x.device)
@@ -218,6 +221,26 @@ class unit_agcn(nn.Module):
         y, P = F.agcn_forward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"],
                               st["Wdown"], st["bdown"], st["bn_scale"], st["bn_shift"], st["down_scale"],
                               st["down_shift"])
+        self.last_attention = P
+        return y
+
+
+    def _forward_train(self, x, st):
+        """Batch-statistics BatchNorm forward (model/unit_agcn.py:91-92 with self.training); updates running buffers."""
+        bn = self.bn
+        if bn.momentum is None or not bn.track_running_stats:
+            raise NotImplementedError("unit_agcn: training-mode BatchNorm needs momentum and running statistics")
+        down_bn = None
+        if self._has_down():
+            d = self.down[1]
+            down_bn = (d.weight, d.bias, d.running_mean, d.running_var)
+        y, P = F.agcn_forward_train(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"],
+                                    st["Wdown"], st["bdown"], (bn.weight, bn.bias, bn.running_mean, bn.running_var),
+                                    down_bn, bn.momentum, bn.eps)
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            if down_bn is not None:
+                self.down[1].num_batches_tracked += 1
         self.last_attention = P
         return y
 
@@ -276,20 +299,33 @@ class Unit2D(nn.Module):
     def forward(self, x):
         if getattr(x, "_stgcn_fused_for", None) is self:
             return x                      # produced by the fused stem kernel in unit_agcn.forward
-        _require_inference(self, x)       # eval: dropout is the identity (model/net.py:48)
+        _check_input(self, x)
         if x.shape[1] != self.conv.in_channels:
             raise RuntimeError(f"Unit2D: expected {self.conv.in_channels} input channels, got {x.shape[1]}")
         if self.dim == 3:
             x = x.transpose(2, 3)
         x = x.contiguous()
         N, Cin, T, V = x.shape
-        st = self._staged(x.device)
         mode = self.math_mode
         if mode != MATH_F32_VALU and not F.tcn_supported(Cin, self.conv.out_channels, T, V, self.kernel_size,
                                                          self.stride, mode):
             mode = MATH_F32_VALU
-        y = F.tcn_forward_packed(x, self._packed(st, mode), st["shift"], self.conv.out_channels,
-                                 self.kernel_size, self.stride, mode, self.out_bf16)
+        if self.training:
+            if self.dropout.p > 0:
+                x = self.dropout(x)          # torch's RNG-driven op (the stem always uses p = 0, model/net.py:45)
+            bn = self.bn
+            if bn.momentum is None or not bn.track_running_stats:
+                raise NotImplementedError("Unit2D: training-mode BatchNorm needs momentum and running statistics")
+            c = self.conv
+            W = c.weight.detach().reshape(c.out_channels, c.in_channels, self.kernel_size).contiguous()
+            y = F.tcn_forward_train(x, W, c.bias, (bn.weight, bn.bias, bn.running_mean, bn.running_var), self.stride,
+                                    mode, bn.momentum, bn.eps)
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+        else:
+            st = self._staged(x.device)
+            y = F.tcn_forward_packed(x, self._packed(st, mode), st["shift"], self.conv.out_channels,
+                                     self.kernel_size, self.stride, mode, self.out_bf16)
         if self.dim == 3:
             y = y.transpose(2, 3).contiguous()
         return y

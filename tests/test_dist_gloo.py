@@ -40,7 +40,8 @@ def _worker(rank, world, port, n_total, q):
     stats = sd.all_reduce_stats(sd.step_stats(out, mine.shape[0]))
     tmax = sd.max_over_ranks(0.1 * (rank + 1), torch.device("cpu"))
     sd.barrier()
-    q.put((rank, sd.shard_bounds(n_total, rank, world), out, stats, tmax))
+    # numpy (pickled by value): torch tensors would travel as shared-memory handles that die with this process
+    q.put((rank, sd.shard_bounds(n_total, rank, world), out.numpy(), stats.numpy(), tmax))
     torch.distributed.destroy_process_group()
 
 
@@ -66,11 +67,11 @@ def test_two_rank_sharding_and_stats(n_total):
     tp = so.tcn_params_from_state(sub_state(g, "tcn."))
     x = torch.randn(n_total, 128, 6, 22, generator=torch.Generator().manual_seed(3))
     full = so.tcn_forward(x, tp)
-    assert torch.equal(torch.cat([res[0][2], res[1][2]]), full)          # clip independence across ranks
+    assert torch.equal(torch.cat([torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2])]), full)   # clip independence
     ref = sd.step_stats(full, n_total)
     for r in res:
-        assert torch.allclose(r[3], ref, rtol=1e-5, atol=1e-4)           # all-reduced == whole-batch statistics
-        assert r[3][0].item() == n_total
+        assert torch.allclose(torch.from_numpy(r[3]), ref, rtol=1e-5, atol=1e-4)   # all-reduced == whole-batch statistics
+        assert float(r[3][0]) == n_total
         assert r[4] == pytest.approx(0.2)                                # MAX over ranks of the step time
 
 

@@ -261,7 +261,7 @@ def test_errors_are_loud(dev):
     from stgcn_amd import Unit2D, functional as F, StgcnError
     m = Unit2D(8, 8, kernel_size=3).to(dev)
     with pytest.raises(NotImplementedError):
-        m.train()(torch.zeros(1, 8, 4, 4, device=dev))
+        m.train()(torch.zeros(1, 8, 4, 4, device=dev))   # autograd would be needed: refused
     with pytest.raises(RuntimeError):
         m.eval()(torch.zeros(1, 8, 4, 4))            # CPU tensor: no fallback
     with pytest.raises(ValueError):
@@ -323,3 +323,60 @@ def test_step_stats_kernel_matches_torch(dev):
     p16 = out.to(torch.bfloat16)[:, :, 0, 0].double().cpu()
     assert torch.allclose(got16[1:3].double(), torch.tensor([p16.sum().item(), p16.square().sum().item()], dtype=torch.float64),
                           rtol=1e-4, atol=1e-2)
+
+
+# ---------------------------------------------------------------------------------------
+# training-mode forward (batch-statistics BatchNorm), against the reference's own train-mode outputs
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", sorted(GCN_CASES))
+def test_agcn_train_forward_vs_golden(case, dev):
+    g = load_golden(case)
+    cin, cout = GCN_CASES[case]
+    m = build_gcn(g, cin, cout, dev).train()
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x"]).to(dev))
+    parity_gate(m.last_attention, g["P_train"], 1e-4, f"{case} P")
+    parity_gate(y, g["y_train"], 1e-4, f"{case} y (train)")
+    sd = m.state_dict()
+    for k, v in g.items():
+        if k.startswith("after_train.gcn."):
+            name = k[len("after_train.gcn."):]
+            if "num_batches" in name:
+                assert int(sd[name]) == int(v)
+            else:
+                parity_gate(sd[name], v, 1e-4, f"{case} {name}")
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3", "f32_valu"])
+@pytest.mark.parametrize("case", sorted(TCN_CASES))
+def test_tcn_train_forward_vs_golden(case, math, dev):
+    g = load_golden(case)
+    cin, cout, K, stride, bias = TCN_CASES[case]
+    m = build_tcn(g, cin, cout, K, stride, bias, dev, math).train()
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x"]).to(dev))
+    parity_gate(y, g["y_train"], 1e-4, f"{case} {math} (train)")
+    sd = m.state_dict()
+    parity_gate(sd["bn.running_mean"], g["after_train.tcn.bn.running_mean"], 1e-4, "running_mean")
+    parity_gate(sd["bn.running_var"], g["after_train.tcn.bn.running_var"], 1e-4, "running_var")
+    assert int(sd["bn.num_batches_tracked"]) == int(g["after_train.tcn.bn.num_batches_tracked"])
+
+
+def test_stem_train_forward_vs_golden(dev):
+    g = load_golden("stem_shre_T180")
+    gcn = build_gcn(g, 3, 128, dev).train()
+    tcn = build_tcn(g, 128, 128, 9, 1, True, dev).train()
+    x = torch.from_numpy(g["skeleton"]).to(dev).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        z = tcn(gcn(x)).cpu()
+    scale = float(g["z_train_absmax"])
+    err = (gather_flat(z, g["z_train_idx"]).double() - torch.from_numpy(g["z_train_val"]).double()).abs().max().item()
+    assert err <= 1e-4 * scale
+    parity_gate(tcn.bn.running_var, g["after_train.tcn.bn.running_var"], 1e-4, "tcn running_var after one step")
+
+
+def test_backward_is_refused_loudly(dev):
+    from stgcn_amd import Unit2D
+    m = Unit2D(16, 128, kernel_size=9).to(dev).train()
+    with pytest.raises(NotImplementedError, match="backward"):
+        m(torch.zeros(1, 16, 8, 22, device=dev))          # grad enabled + trainable parameters

@@ -199,36 +199,49 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         STGCN_STAMP(t_tile1)
         STGCN_ACC(0, t_tile0, t_tile1)
 
+        // operand fetch helpers (LDS -> registers)
+        auto load_a = [&](Frag2<TERMS> &a, const char *aslot, int tt) {
+            if (STGCN_ABL(16)) return;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                a.hi[m] = *reinterpret_cast<const uint4 *>(aslot + (tt * 8 + m * 2) * FRAG);
+                if constexpr (TERMS == 3) a.lo[m] = *reinterpret_cast<const uint4 *>(aslot + (tt * 8 + m * 2 + 1) * FRAG);
+            }
+        };
+        auto load_b = [&](Frag2<TERMS> &b, const char *img, int tap) {
+            if (STGCN_ABL(8)) return;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = lds_off(prow[j] + tap * V, h);
+                b.hi[j] = *reinterpret_cast<const uint4 *>(img + off);
+                if constexpr (TERMS == 3) b.lo[j] = *reinterpret_cast<const uint4 *>(img + img_bytes + off);
+            }
+        };
+
         for (int ch = 0; ch < nch; ++ch) {
             const char *cur = (ch & 1) ? buf1 : buf0;
             char *nxt = (ch & 1) ? buf0 : buf1;
             const bool last = ch + 1 == nch;
             if (last && next_tile < ntiles) dma_features(next_tile);   // Fs is idle during the last chunk
+            // Software pipeline: the fragments of tap t+1 are fetched before the MFMAs of tap t are issued (hipcc
+            // otherwise reads right in front of each use and every tap pays an LDS round trip).  The activation
+            // fragments also cross the stage barriers (the chunk image is stable for the whole chunk); the weight
+            // fragments of a new stage can only be read after the barrier that publishes its DMA.
+            Frag2<TERMS> a_cur = {}, b_cur = {}, a_nxt = {}, b_nxt = {};
+            load_b(b_cur, cur, 0);
 #pragma unroll
             for (int st = 0; st < KT4 / STG; ++st, ++gs) {
                 STGCN_STAMP(t_s0)
                 const char *aslot = ring + (gs & 1) * STAGE_BYTES + (wm * 4) * FRAG + lane * 16;
+                load_a(a_cur, aslot, 0);
 #pragma unroll
                 for (int tt = 0; tt < STG; ++tt) {
                     const int tap = st * STG + tt;
-                    Frag2<TERMS> a, b;
-                    if (!STGCN_ABL(16)) {
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            a.hi[m] = *reinterpret_cast<const uint4 *>(aslot + (tt * 8 + m * 2) * FRAG);
-                            if constexpr (TERMS == 3)
-                                a.lo[m] = *reinterpret_cast<const uint4 *>(aslot + (tt * 8 + m * 2 + 1) * FRAG);
-                        }
-                    }
-                    if (!STGCN_ABL(8)) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int off = lds_off(prow[j] + tap * V, h);
-                            b.hi[j] = *reinterpret_cast<const uint4 *>(cur + off);
-                            if constexpr (TERMS == 3) b.lo[j] = *reinterpret_cast<const uint4 *>(cur + img_bytes + off);
-                        }
-                    }
-                    if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a, b);
+                    if (tt + 1 < STG) load_a(a_nxt, aslot, tt + 1);
+                    if (tap + 1 < KT4) load_b(b_nxt, cur, tap + 1);
+                    if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a_cur, b_cur);
+                    __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 8 : 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TERMS == 3 ? 12 : 4, 0);
                     // next weight stage -> other ring slot (its readers passed the last barrier); issued behind the
                     // first tap's MFMAs so the DMA's issue cost does not delay the start of the stage
                     if (tt == 0) dma_stage(gs + 1);
@@ -236,6 +249,8 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                     //  for that half, were both measured neutral-to-negative.)
                     if (tap < PB && !STGCN_ABL(1))  // (last chunk: recomputes chunk nch-1 into the idle buffer; discarded)
                         produce_block(nxt, min(ch + 1, nch - 1), min(wave + 8 * tap, nblk - 1));
+                    a_cur = a_nxt;
+                    b_cur = b_nxt;
                 }
                 STGCN_STAMP(t_s1)
                 dma_wait();

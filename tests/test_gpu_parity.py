@@ -380,3 +380,23 @@ def test_backward_is_refused_loudly(dev):
     m = Unit2D(16, 128, kernel_size=9).to(dev).train()
     with pytest.raises(NotImplementedError, match="backward"):
         m(torch.zeros(1, 16, 8, 22, device=dev))          # grad enabled + trainable parameters
+
+
+@pytest.mark.parametrize("N", [17, 33])
+def test_persistent_kernel_uneven_tiles(N, dev):
+    """More tiles than CUs but not a multiple (some workgroups of the persistent kernel loop twice, most once):
+    the fused bf16x3 stem must equal the two-stage path and three of its clips the fp64 oracle."""
+    from stgcn_amd import enable_stem_fusion
+    from stgcn_amd.graphs import SHREGraph
+    from oracle import stgcn_oracle as so
+    A = torch.from_numpy(SHREGraph("spatial").A.astype(np.float32))
+    gcn, tcn, gp, tp, gen = _random_stem(22, A, 300 + N, dev)
+    x = torch.randn(N, 3, 180, 22, generator=gen)
+    with torch.no_grad():
+        two = tcn(gcn(x.to(dev)))
+        enable_stem_fusion(gcn, tcn)
+        fused = tcn(gcn(x.to(dev)))
+    parity_gate(fused, two, 1e-4, "fused vs two-stage")
+    sel = [0, N // 2, N - 1]
+    ref = so.stem_forward(x[sel].double(), gp.to(torch.float64), tp.to(torch.float64))
+    parity_gate(fused[sel], ref, 1e-4, "clips vs oracle")

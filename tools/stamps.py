@@ -35,3 +35,6 @@ print(f"math={a.math} abl={a.abl}: per-wave total stamped cycles: mean {tot.mean
 for i, nm in enumerate(names):
     v = t[:, :, i]
     print(f"  {nm:20s} mean {v.mean():10.0f}  ({100 * v.mean() / tot.mean():5.1f} %)  min {v.min():10.0f} max {v.max():10.0f}")
+print("per-wave (workgroup 0): stage compute / barrier wait")
+for w in range(8):
+    print(f"  wave {w}: compute {t[0, w, 1]:10.0f}  wait {t[0, w, 2]:10.0f}  epilogue {t[0, w, 3]:8.0f}")

@@ -20,12 +20,11 @@
 //   weights     : packed [mb][chunk][tap][hi|lo][lane][8 bf16] with the BN scale folded in before the
 //                 split; a lane streams 16 B per fragment straight from L2, two taps ahead (the two
 //                 pixel-half waves of a channel half read the same fragments -> L1 hits).
-//   producer    : the next chunk is produced while the current one is consumed, in the SAME basic block
-//                 as the MFMAs (tap loop fully unrolled for K = 9), two channels per tap, so the VALU work
-//                 issues in the shadow of the wave's own MFMAs instead of as a separate phase.
-//                 Fused stem: relu(W12 . feat + b) from the 12 graph-conv features each thread keeps in
-//                 registers for its 1-3 tile pixels (W12 is wave-uniform: scalar loads).
-//                 Stand-alone temporal conv: fp32 activations loaded from HBM/L2, coalesced along pixels.
+//   producer    : the next chunk is staged while the current one is consumed, in the SAME basic block as the
+//                 MFMAs (tap loop fully unrolled for K = 9).  Stand-alone temporal conv (tcn_mfma_bf16_kernel):
+//                 fp32 activations loaded from HBM/L2, coalesced along pixels, split and stored by the VALU.
+//                 Fused stem at 128-pixel tiles (stem_mfma_bf16_kernel): relu(W12 . features) on the matrix cores
+//                 from an LDS feature tile; the 256-pixel persistent form lives in stem_bf16_v4.hip.
 #include "bf16_common.h"
 
 namespace stgcn {
@@ -62,16 +61,17 @@ __global__ void tcn_pack_bf16_kernel(const float *__restrict__ W, const float *_
 }
 
 // -----------------------------------------------------------------------------------------------
-// FUSED = false : x is the (N,Cin,T,V) fp32 input of the temporal conv
-// FUSED = true  : x is the (N,3,T,V) skeleton, P the attention matrices, W12 the folded graph conv
-// KT            : 9 = tap loop fully unrolled with the producer interleaved; 0 = any K (runtime loop)
+// Stand-alone temporal conv block (Unit2D) on the bf16 matrix cores: x is the (N,Cin,T,V) fp32 input.
+// Each thread owns JPR tile pixels; it loads 8 channels of them (coalesced along pixels), splits them into bf16
+// hi/lo and stores one 16-byte group per image.  KT = 9: tap loop fully unrolled with that staging interleaved
+// (loads at taps 0 and 3, stores at taps 3 and 7); KT = 0: any K, runtime tap loop, staging between chunks.
+// act_lo = 0 for ReLU, -inf for the raw pre-activation output (training-mode BatchNorm).
 // -----------------------------------------------------------------------------------------------
-template <int JPR, int TERMS, bool BF16OUT, bool FUSED, int KT>
+template <int JPR, int TERMS, bool BF16OUT, int KT>
 __global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
-    const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ W12,
-    const uint4 *__restrict__ Wp, const float *__restrict__ shift, void *y, int Cin, int Cout, int T, int V,
-    int Krt, int stride, int Tout, int ROWS /* pixel rows per image */, int abl, float lo) {
-    constexpr int CIN0 = 3, S = 3, F = 12;
+    const float *__restrict__ x, const uint4 *__restrict__ Wp, const float *__restrict__ shift, void *y, int Cin,
+    int Cout, int T, int V, int Krt, int stride, int Tout, int ROWS /* pixel rows per image */, int abl,
+    float act_lo) {
     const int K = KT ? KT : Krt;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     const int tid = threadIdx.x;
@@ -101,75 +101,17 @@ __global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
         jdst[jj] = wr ? jcol[jj] : ROWS - 1;
     }
 
-    // ---- producer state ------------------------------------------------------------------
-    float feat[FUSED ? JPR : 1][F];
-    float pv[JPR][8];  // 8 channels of the unit being assembled (fused: computed; else: loaded)
-    const float *xn = x + (size_t)n * (FUSED ? CIN0 : Cin) * TV;
-    if constexpr (FUSED) {
-        float *Ps = reinterpret_cast<float *>(buf1);  // [S][V][V]   (the buf1 region is free until chunk 1)
-        float *Xs = Ps + S * V * V;                   // [CIN0][span]
-        const float *Pn = P + (size_t)n * S * V * V;
-        for (int e = tid; e < S * V * V; e += NT) Ps[e] = Pn[e];
-        for (int e = tid; e < CIN0 * g.span; e += NT) {
-            const int k = e / g.span, j = e - k * g.span;
-            const int gi = g.origin + j;
-            Xs[e] = (gi >= 0 && gi < TV) ? xn[(size_t)k * TV + gi] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int jj = 0; jj < JPR; ++jj) {
-#pragma unroll
-            for (int f = 0; f < F; ++f) feat[jj][f] = 0.f;
-            if (jok[jj]) {
-                const int j = jcol[jj];
-                const int fr = j / V, w = j - fr * V;
-                const float *xr = Xs + fr * V;
-                const float *pc = Ps + w;
-#pragma unroll 2
-                for (int v = 0; v < V; ++v) {
-                    float xv[CIN0];
-#pragma unroll
-                    for (int k = 0; k < CIN0; ++k) xv[k] = xr[k * g.span + v];
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const float pw = pc[(s * V + v) * V];
-#pragma unroll
-                        for (int k = 0; k < CIN0; ++k)
-                            feat[jj][s * CIN0 + k] = fmaf(xv[k], pw, feat[jj][s * CIN0 + k]);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < CIN0; ++k) feat[jj][S * CIN0 + k] = Xs[k * g.span + j];
-            }
-        }
-    }
-
-    // value of channel c (chunk ch) at this thread's pixels -> pv[jj][slot]   (fused path)
-    auto compute_channel = [&](int ch, int c, int slot) {
-        if constexpr (FUSED) {
-            const int o = min(ch * CCB + c, Cin - 1);      // clamp: the pass after the last chunk is discarded
-            const float *wr = W12 + (size_t)o * W12P;      // wave-uniform address: scalar loads
-#pragma unroll
-            for (int jj = 0; jj < JPR; ++jj) {
-                float a = wr[F];
-#pragma unroll
-                for (int f = 0; f < F; ++f) a = fmaf(wr[f], feat[jj][f], a);
-                pv[jj][slot] = jok[jj] ? fmaxf(a, 0.f) : 0.f;  // outside the clip the conv sees zero padding
-            }
-        }
-    };
-    // 8 channels (unit u of chunk ch) of this thread's pixels, straight from global memory (stand-alone path)
+    // ---- staging of the activation chunk -------------------------------------------------------
+    float pv[JPR][8];  // 8 channels (one unit) of this thread's pixels, in flight from HBM/L2
+    const float *xn = x + (size_t)n * Cin * TV;
     auto load_unit = [&](int ch, int u) {
-        if constexpr (!FUSED) {
-            const int c0 = min(ch, nch - 1) * CCB + u * 8;
+        const int c0 = min(ch, nch - 1) * CCB + u * 8;   // (past the last chunk: re-read it; discarded)
 #pragma unroll
-            for (int jj = 0; jj < JPR; ++jj)
+        for (int jj = 0; jj < JPR; ++jj)
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    pv[jj][i] = jok[jj] ? xn[(size_t)(c0 + i) * TV + g.origin + jcol[jj]] : 0.f;
-        }
+            for (int i = 0; i < 8; ++i)
+                pv[jj][i] = jok[jj] ? xn[(size_t)(c0 + i) * TV + g.origin + jcol[jj]] : 0.f;
     };
-    // split pv into hi/lo and store it as unit u of `buf`
     auto store_unit = [&](char *buf, int u) {
 #pragma unroll
         for (int jj = 0; jj < JPR; ++jj) {
@@ -179,15 +121,6 @@ __global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
             *reinterpret_cast<uint4 *>(buf + off) = hi;
             if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(buf + img_bytes + off) = lo;
         }
-    };
-    auto produce_unit_now = [&](char *buf, int ch, int u) {  // whole unit at once (prologue / generic-K path)
-        if constexpr (FUSED) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) compute_channel(ch, u * 8 + i, i);
-        } else {
-            load_unit(ch, u);
-        }
-        store_unit(buf, u);
     };
 
     // ---- consumer state ------------------------------------------------------------------
@@ -208,9 +141,11 @@ __global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
-    produce_unit_now(buf0, 0, 0);
-    produce_unit_now(buf0, 0, 1);
-    __syncthreads();  // chunk 0 visible; (fused) every wave is done with Ps/Xs in the buf1 region
+    load_unit(0, 0);
+    store_unit(buf0, 0);
+    load_unit(0, 1);
+    store_unit(buf0, 1);
+    __syncthreads();  // chunk 0 visible
 
     // weight fragments: [m].hi/.lo of flat k index kidx = ch*K + tap at wpm[m][(kidx*2 + img)*64]
     const int nk = nch * K;
@@ -246,24 +181,17 @@ __global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
         Frag2<TERMS> b0 = {}, b1 = {};
         load_b(b0, cur, 0);
         if constexpr (KT == 9) {
-            // ---- fully unrolled: one basic block per chunk, producer slices between the MFMAs ----
+            // ---- fully unrolled: one basic block per chunk, staging slices between the MFMAs ----
 #define STGCN_TAP(TAP)                                                                                   \
     do {                                                                                                 \
         load_a(a2, kidx + 2);                                                                            \
         load_b(b1, cur, (TAP) + 1 < 9 ? (TAP) + 1 : (TAP));                                              \
         if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a0, b0);                                          \
         if (!STGCN_ABL(1)) {                                                                             \
-            if constexpr (FUSED) {                                                                       \
-                if ((TAP) < 8) {                                                                         \
-                    compute_channel(ch + 1, 2 * (TAP), (2 * (TAP)) & 7);                                 \
-                    compute_channel(ch + 1, 2 * (TAP) + 1, (2 * (TAP) + 1) & 7);                         \
-                }                                                                                        \
-            } else {                                                                                     \
-                if ((TAP) == 0) load_unit(ch + 1, 0);                                                    \
-            }                                                                                            \
+            if ((TAP) == 0) load_unit(ch + 1, 0);                                                        \
             if ((TAP) == 3) {                                                                            \
                 store_unit(nxt, 0);                                                                      \
-                if constexpr (!FUSED) load_unit(ch + 1, 1);                                              \
+                load_unit(ch + 1, 1);                                                                    \
             }                                                                                            \
             if ((TAP) == 7) store_unit(nxt, 1);                                                          \
         }                                                                                                \
@@ -292,8 +220,10 @@ __global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
                 b0 = b1;
             }
             if (ch + 1 < nch) {
-                produce_unit_now(nxt, ch + 1, 0);
-                produce_unit_now(nxt, ch + 1, 1);
+                load_unit(ch + 1, 0);
+                store_unit(nxt, 0);
+                load_unit(ch + 1, 1);
+                store_unit(nxt, 1);
             }
         }
         __syncthreads();
@@ -312,12 +242,11 @@ __global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
-                if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[m][j][r] + sh, lo));
+                if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[m][j][r] + sh, act_lo));
             }
         }
     }
 }
-
 
 // -----------------------------------------------------------------------------------------------
 // Fused stem on the bf16 matrix cores.  Same consumer as above; the producer is itself an MFMA:
@@ -618,18 +547,13 @@ struct Bf16Plan {
     size_t lds = 0;
 };
 
-inline bool plan_bf16(int Cin, int Cout, int V, int K, int stride, int Tout, int terms, bool fused, Bf16Plan &pl) {
+inline bool plan_bf16(int Cin, int Cout, int V, int K, int stride, int Tout, int terms, Bf16Plan &pl) {
     if (Cin % CCB != 0 || Cout % 128 != 0) return false;
     const int rows = rows_needed(V, K, stride, Tout);
     const int jpr = ceil_div(rows - 1, NT);
     if (jpr > 3) return false;
     const size_t buf = (size_t)rows * PXB * (terms == 3 ? 2 : 1);
-    size_t second = buf;
-    if (fused) {  // Ps + Xs live where buf1 starts until chunk 1 is produced
-        const size_t px = ((size_t)3 * V * V + (size_t)3 * rows) * 4;
-        if (px > second) second = px;
-    }
-    const size_t lds = buf + second;
+    const size_t lds = 2 * buf;
     if (lds > (size_t)kLdsBytes) return false;
     pl.jpr = jpr;
     pl.rows = rows;
@@ -637,33 +561,30 @@ inline bool plan_bf16(int Cin, int Cout, int V, int K, int stride, int Tout, int
     return true;
 }
 
-template <int JPR, int TERMS, bool FUSED, int KT>
-int launch_variant(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y,
-                   int N, int Cin, int Cout, int T, int V, int K, int stride, int Tout, const Bf16Plan &pl,
-                   bool bf16out, float lo, hipStream_t st) {
+template <int JPR, int TERMS, int KT>
+int launch_variant(const float *x, const uint4 *Wp, const float *shift, void *y, int N, int Cin, int Cout, int T, int V,
+                   int K, int stride, int Tout, const Bf16Plan &pl, bool bf16out, float act_lo, hipStream_t st) {
     const dim3 grid(ceil_div(Tout * V, NPB), Cout / 128, N);
     if (bf16out) {
-        auto kern = tcn_mfma_bf16_kernel<JPR, TERMS, true, FUSED, KT>;
+        auto kern = tcn_mfma_bf16_kernel<JPR, TERMS, true, KT>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
-        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, Cin, Cout, T, V, K, stride, Tout,
-                           pl.rows, ablate_mask(), lo);
+        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, Wp, shift, y, Cin, Cout, T, V, K, stride, Tout, pl.rows,
+                           ablate_mask(), act_lo);
     } else {
-        auto kern = tcn_mfma_bf16_kernel<JPR, TERMS, false, FUSED, KT>;
+        auto kern = tcn_mfma_bf16_kernel<JPR, TERMS, false, KT>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
-        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, Cin, Cout, T, V, K, stride, Tout,
-                           pl.rows, ablate_mask(), lo);
+        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, Wp, shift, y, Cin, Cout, T, V, K, stride, Tout, pl.rows,
+                           ablate_mask(), act_lo);
     }
     STGCN_LAUNCH_CHECK("tcn_mfma_bf16_kernel");
     return STGCN_OK;
 }
 
-template <int TERMS, bool FUSED>
-int dispatch_tcn(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y, int N,
-             int Cin, int Cout, int T, int V, int K, int stride, int Tout, const Bf16Plan &pl, bool bf16out,
-             float lo, hipStream_t st) {
-#define GO(JPR, KT)                                                                                             \
-    return launch_variant<JPR, TERMS, FUSED, KT>(x, P, W12, Wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, \
-                                                 bf16out, lo, st)
+template <int TERMS>
+int dispatch_tcn(const float *x, const uint4 *Wp, const float *shift, void *y, int N, int Cin, int Cout, int T, int V,
+                 int K, int stride, int Tout, const Bf16Plan &pl, bool bf16out, float act_lo, hipStream_t st) {
+#define GO(JPR, KT) \
+    return launch_variant<JPR, TERMS, KT>(x, Wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, act_lo, st)
     if (K == 9) {
         if (pl.jpr == 1) GO(1, 9);
         if (pl.jpr == 2) GO(2, 9);
@@ -688,7 +609,7 @@ bool bf16_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned
         return Cin == Cout && stride == 1 && plan_stem_bf16(Cin, V, K, T, terms, sp);
     }
     Bf16Plan pl;
-    return plan_bf16(Cin, Cout, V, K, stride, Tout, terms, false, pl);
+    return plan_bf16(Cin, Cout, V, K, stride, Tout, terms, pl);
 }
 
 bool bf16_packs(int Cin, int Cout, unsigned math) {
@@ -718,14 +639,14 @@ int launch_tcn_bf16(const float *x, const float *P, const float *W12, const void
         return dispatch_stem<1>(x, P, W12, (const uint4 *)Wp, shift, y, N, Cin, T, V, K, sp, bf16out, st);
     }
     Bf16Plan pl;
-    if (Tout < 1 || !plan_bf16(Cin, Cout, V, K, stride, Tout, terms, fused, pl))
+    if (Tout < 1 || !plan_bf16(Cin, Cout, V, K, stride, Tout, terms, pl))
         return fail(STGCN_ERR_UNSUPPORTED,
                     "bf16 MFMA kernel does not cover Cin=%d Cout=%d V=%d K=%d stride=%d T=%d (needs Cin%%16==0, "
                     "Cout%%128==0, tile rows that fit LDS)", Cin, Cout, V, K, stride, T);
     const uint4 *wp = (const uint4 *)Wp;
-    const float lo = (flags & STGCN_RAW) ? -__builtin_huge_valf() : 0.f;  // raw = pre-activation (training-mode BN)
-    if (terms == 3) return dispatch_tcn<3, false>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, lo, st);
-    return dispatch_tcn<1, false>(x, P, W12, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, lo, st);
+    const float act_lo = (flags & STGCN_RAW) ? -__builtin_huge_valf() : 0.f;  // raw = pre-activation (training-mode BN)
+    if (terms == 3) return dispatch_tcn<3>(x, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, act_lo, st);
+    return dispatch_tcn<1>(x, wp, shift, y, N, Cin, Cout, T, V, K, stride, Tout, pl, bf16out, act_lo, st);
 }
 
 }  // namespace stgcn

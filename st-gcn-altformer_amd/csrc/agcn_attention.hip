@@ -14,7 +14,7 @@
 //
 // Both are HBM-read-bound in principle (x is read once: 4*Cin*T*V bytes per clip) and tiny next to
 // the temporal conv; P (N,S,V,V) is written once.
-#include "common.h"
+#include "bf16_common.h"
 
 namespace stgcn {
 
@@ -208,16 +208,18 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
 
     // Optional feature pass for the fused stem (Cin = 3, S = 3 only): per pixel (t,w) the 12 graph-conv
     // features [u_0, u_1, u_2, x] with u_s[k] = sum_v x[k,t,v] P_s[v,w]  (model/unit_agcn.py:87-88), then a
-    // constant 1 that multiplies the folded bias and 3 zeros -> feat[n][t*V+w][16], 64 B per pixel, coalesced.
+    // constant 1 that multiplies the folded bias and 3 zeros; the 16 values are split into bf16 hi + lo residual
+    // (the operand form of the stem kernel's matrix-core producer) -> feat[n][t*V+w] = 64 B per pixel, coalesced:
+    // [hi f0-7][hi f8-15][lo f0-7][lo f8-15].
     if (feat == nullptr) return;
     float *Xf = U;  // [3][tcf*V], reuses the dead Gram region
     const int TCF = (R * R) / (3 * V);
     // Each lane builds one 64-byte feature row; storing it directly is 16 B per lane at a 64-B stride (store-issue
     // bound, measured ~4 B/clk/CU).  Instead the wave parks its 64 rows (4 KiB) in a private LDS slice and writes
     // them back out lane-linear: four fully coalesced 1-KiB stores.
-    float4 *slice = reinterpret_cast<float4 *>(smem + feat_slice_off) + (tid >> 6) * 256;
+    uint4 *slice = reinterpret_cast<uint4 *>(smem + feat_slice_off) + (tid >> 6) * 256;
     const int lane = tid & 63;
-    float4 *fo = reinterpret_cast<float4 *>(feat) + (size_t)n * T * V * 4;
+    uint4 *fo = reinterpret_cast<uint4 *>(feat) + (size_t)n * T * V * 4;
     for (int t0 = 0; t0 < T; t0 += TCF) {
         const int tcf = min(TCF, T - t0);
         const int px = tcf * V;
@@ -245,14 +247,19 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
                         u[s3 * 3 + 2] = fmaf(x2, pw, u[s3 * 3 + 2]);
                     }
                 }
-                slice[lane * 4 + 0] = make_float4(u[0], u[1], u[2], u[3]);
-                slice[lane * 4 + 1] = make_float4(u[4], u[5], u[6], u[7]);
-                slice[lane * 4 + 2] = make_float4(u[8], Xf[p], Xf[px + p], Xf[2 * px + p]);
-                slice[lane * 4 + 3] = make_float4(1.f, 0.f, 0.f, 0.f);
+                const float fa[8] = {u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]};
+                const float fb[8] = {u[8], Xf[p], Xf[px + p], Xf[2 * px + p], 1.f, 0.f, 0.f, 0.f};
+                uint4 ha, la, hb, lb;  // bf16 hi / lo residual of features 0-7 and 8-15
+                bf16k::split8(fa, ha, la);
+                bf16k::split8(fb, hb, lb);
+                slice[lane * 4 + 0] = ha;
+                slice[lane * 4 + 1] = hb;
+                slice[lane * 4 + 2] = la;
+                slice[lane * 4 + 3] = lb;
             }
             // wave-private: same wave reads what it wrote (the compiler's lgkmcnt wait orders it)
             const int nrow = min(64, px - p0);
-            float4 *dst = fo + ((size_t)t0 * V + p0) * 4;
+            uint4 *dst = fo + ((size_t)t0 * V + p0) * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int idx = j * 64 + lane;

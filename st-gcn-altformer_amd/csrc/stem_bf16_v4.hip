@@ -9,14 +9,18 @@
 //     wave, staged 3 taps (one "stage") ahead into the other half of a 2-stage ring; a stage ends with
 //     vmcnt(0) + barrier.  No weight traffic through VGPRs/L1 (it saturated the vector L1 before).
 //   * the 12 graph-conv features per pixel are NOT recomputed per tile: the attention kernel emits them
-//     once per clip (feat[n][pixel][16], 64 B per pixel) and the tile's rows are DMA'd into the feature
-//     tile Fs; rows outside the clip are zeroed (the temporal conv's zero padding).
+//     once per clip, already split into bf16 hi/lo (feat[n][pixel] = 64 B: [hi f0-7][hi f8-15][lo f0-7]
+//     [lo f8-15]) and the tile's rows are DMA'd into the feature tile Fs; rows outside the clip are zeroed
+//     (the temporal conv's zero padding).
 //   * persistent: grid = one workgroup per CU looping over tiles; the next tile's feature rows are DMA'd
 //     during the last channel chunk of the current tile (Fs is idle then), so a tile's serial part is
 //     only its epilogue stores + the production of channel chunk 0.
 //
-// Everything else (LDS image layout, k-step = 16 channels of one tap, 2x2 MFMA blocks per wave, MFMA
-// producer relu(W12 . Fs^T) via v_mfma_f32_16x16x4_f32, hi/lo split) is as described in tcn_bf16.hip.
+//   * the producer relu(W12 . Fs^T) runs on the bf16 matrix cores as well (two v_mfma_f32_16x16x32_bf16 per
+//     16x16 block, all four hi/lo products).
+//
+// Everything else (LDS image layout, k-step = 16 channels of one tap, 2x2 MFMA blocks per wave, hi/lo split of the
+// produced activations) is as described in tcn_bf16.hip.
 #include "bf16_common.h"
 
 namespace stgcn {
@@ -31,6 +35,7 @@ constexpr int KT4 = 9;     // temporal taps (the only kernel size this kernel is
 constexpr int STG = 3;     // taps per weight stage
 constexpr int FRAG = 1024; // bytes of one packed MFMA weight fragment (64 lanes x 16 B)
 constexpr int STAGE_BYTES = STG * 8 * FRAG;
+constexpr int EPI_BYTES = 8192;  // epilogue staging per wave: 32 channels x 64 pixels fp32
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -75,11 +80,13 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     const int img_bytes = ROWS * PXB;
     const int buf_bytes = img_bytes * (TERMS == 3 ? 2 : 1);
     // LDS carve
-    float *W12s = reinterpret_cast<float *>(smem4);                 // [C][16]: folded graph conv, all C produced channels
+    uint4 *W12q = reinterpret_cast<uint4 *>(smem4);                 // folded graph conv as bf16 hi/lo: 4 planes of [C] x 16 B
     char *ring = smem4 + C * W12P * 4;                              // 2 stages x 3 taps x 8 fragments
     char *buf0 = ring + 2 * STAGE_BYTES;
     char *buf1 = buf0 + buf_bytes;
-    float4 *Fs = reinterpret_cast<float4 *>(buf1 + buf_bytes);      // 4 planes of [ROWS] float4
+    // (the image buffers double as the epilogue's staging area, 8 KiB per wave; the feature tile is prefetched for
+    //  the next tile while that epilogue runs, so it starts behind BOTH)
+    uint4 *Fs = reinterpret_cast<uint4 *>(buf0 + max(2 * buf_bytes, 8 * EPI_BYTES));  // features as bf16 hi/lo: 4 planes of [ROWS] x 16 B
     // LDS byte addresses for the DMA destinations (M0), derived from the array base by plain arithmetic
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem4;
     const unsigned ring_lds = lds0 + (unsigned)(ring - smem4);
@@ -114,27 +121,31 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             const int gi = g.origin + j;
             if (j >= g.span || gi < 0 || gi >= TV) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) Fs[(size_t)q * ROWS + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < 4; ++q) Fs[(size_t)q * ROWS + j] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
     };
 
     // ---- producer: one 16-pixel block of chunk `ch` -> hi/lo images of `buf` -------------------
-    // operands (two ds_read_b128), four chained v_mfma_f32_16x16x4_f32, then ReLU, hi/lo split and two 8-byte LDS
-    // stores.  (Spreading the four MFMAs between the consumer MFMAs and finishing a tap later was measured 3 %
-    // slower: more live registers, same pipe time.)
+    // relu(W12 . f) for 16 channels x 16 pixels as TWO v_mfma_f32_16x16x32_bf16: both operands arrive split into bf16
+    // hi/lo (the features by the attention kernel, W12 at setup) and the 32-deep k axis carries two 16-feature terms,
+    //   MFMA 1:  A = [w_hi | w_hi],  B = [f_hi | f_lo]      MFMA 2:  A = [w_lo | w_lo],  same B
+    // = all four hi/lo products (error ~2^-17 per product, the same order as the hi/lo split of the result that
+    // follows).  32 matrix-pipe cycles per block against 128 for the four v_mfma_f32_16x16x4_f32 used before.
+    // Then ReLU, hi/lo split and two 8-byte LDS stores.  (Spreading the MFMAs between the consumer MFMAs and
+    // finishing a tap later was measured 3 % slower: more live registers, same pipe time.)
     const int pl = lane & 15, pg = lane >> 4;
-    struct Prod { float4 wa, fb; f32x4 d; int p; };
-    auto prod_load = [&](Prod &pr, int ch, int bi) {
-        pr.p = bi * 16 + pl;
-        pr.wa = *reinterpret_cast<const float4 *>(W12s + (ch * CCB + pl) * W12P + 4 * pg);
-        pr.fb = Fs[(size_t)pg * ROWS + pr.p];
-        pr.d = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    auto prod_finish = [&](char *buf, const Prod &pr) {
-        const float v0 = fmaxf(pr.d[0], 0.f), v1 = fmaxf(pr.d[1], 0.f), v2 = fmaxf(pr.d[2], 0.f), v3 = fmaxf(pr.d[3], 0.f);
+    auto produce_block = [&](char *buf, int ch, int bi) {
+        const int p = bi * 16 + pl;
+        const uint4 wh = W12q[(size_t)(pg & 1) * C + ch * CCB + pl];
+        const uint4 wl = W12q[(size_t)(2 + (pg & 1)) * C + ch * CCB + pl];
+        const uint4 fb = Fs[(size_t)pg * ROWS + p];
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, fb), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wl), __builtin_bit_cast(bf16x8, fb), d, 0, 0, 0);
+        const float v0 = fmaxf(d[0], 0.f), v1 = fmaxf(d[1], 0.f), v2 = fmaxf(d[2], 0.f), v3 = fmaxf(d[3], 0.f);
         const unsigned h0 = pack_bf16x2(v0, v1), h1 = pack_bf16x2(v2, v3);
-        const int off = lds_off(pr.p, pg >> 1) + (pg & 1) * 8;
+        const int off = lds_off(p, pg >> 1) + (pg & 1) * 8;
         *reinterpret_cast<uint2 *>(buf + off) = make_uint2(h0, h1);
         if constexpr (TERMS == 3) {
             const unsigned l0 = pack_bf16x2(v0 - bf16_lo_to_f32(h0), v1 - bf16_hi_to_f32(h0));
@@ -142,22 +153,22 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             *reinterpret_cast<uint2 *>(buf + img_bytes + off) = make_uint2(l0, l1);
         }
     };
-    auto produce_block = [&](char *buf, int ch, int bi) {  // un-pipelined form (chunk 0 of a tile)
-        Prod pr;
-        prod_load(pr, ch, bi);
-        pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.x, pr.fb.x, pr.d, 0, 0, 0);
-        pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.y, pr.fb.y, pr.d, 0, 0, 0);
-        pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.z, pr.fb.z, pr.d, 0, 0, 0);
-        pr.d = __builtin_amdgcn_mfma_f32_16x16x4f32(pr.wa.w, pr.fb.w, pr.d, 0, 0, 0);
-        prod_finish(buf, pr);
-    };
     // ---- one-time setup ----------------------------------------------------------------------
-    for (int e = tid; e < C * W12P; e += NT4) W12s[e] = W12[e];
+    for (int e = tid; e < C * 2; e += NT4) {  // W12 -> bf16 hi/lo, planes [hi k0-7][hi k8-15][lo k0-7][lo k8-15] of [C] x 16 B
+        const int c = e >> 1, kh = e & 1;
+        float w8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w8[i] = W12[c * W12P + kh * 8 + i];
+        uint4 hi, lo;
+        split8(w8, hi, lo);
+        W12q[(size_t)kh * C + c] = hi;
+        W12q[(size_t)(2 + kh) * C + c] = lo;
+    }
     int tile = blockIdx.x;
     if (tile < ntiles) dma_features(tile);
     dma_stage(0);
     dma_wait();
-    __syncthreads();                          // W12s, Fs(tile), weight stage 0 landed
+    __syncthreads();                          // W12q, Fs(tile), weight stage 0 landed
     if (tile < ntiles) zero_invalid_rows(tile);
     __syncthreads();
 
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         // wave-instruction writes four 256-B channel rows.
         STGCN_STAMP(t_e0)
         if (!STGCN_ABL(4)) {
-            float *stg = reinterpret_cast<float *>(buf0 + wave * 8192);
+            float *stg = reinterpret_cast<float *>(buf0 + wave * EPI_BYTES);
             const int qw = g.q0 + wn * 64;                       // first pixel of this wave's 64 columns
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -316,246 +327,8 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
 #endif
 }
 
-// =====================================================================================================
-// KF5 — same tile, LDS layout, DMA ring and persistence as KF4, but the 8 waves are SPECIALISED.
-//
-// Measured on KF4: pure-bf16 (1 MFMA per k-step) ran only ~30 % faster than bf16x3 (3 MFMAs): the MFMA time
-// and the rest (operand reads, producer, DMA issue, epilogue) ADD instead of overlapping, because the two waves
-// of a SIMD run the same program between the same barriers and hit each phase together.  Here each SIMD hosts
-//   * one CONSUMER wave (waves 0-3): nothing but operand fragment reads and MFMAs — 64 channels x 128 pixels,
-//     2 x 4 MFMA blocks, 128 accumulator registers; and
-//   * one HELPER wave (waves 4-7): the weight DMA (2 fragments per tap), the MFMA producer of the next channel
-//     chunk (one 16-pixel block per tap), the next tile's feature DMA, and — while the consumers run their
-//     epilogue — chunk 0 of the next tile.
-// so matrix work and everything else sit on different waves of every SIMD by construction.  Rows outside the clip
-// are zeroed in the producer's registers (no fix-up pass over the feature tile, no extra barriers).
-// =====================================================================================================
-template <int PB /* producer blocks per helper wave per chunk, <= 9 */, int TERMS, bool BF16OUT>
-__global__ __launch_bounds__(NT4) void stem_bf16_v5_kernel(
-    const float4 *__restrict__ feat, const float *__restrict__ W12, const uint4 *__restrict__ Wp,
-    const float *__restrict__ shift, void *y, int C, int T, int V, int ROWS, int tiles_per_clip, int ntiles, int abl) {
-    extern __shared__ __attribute__((aligned(16))) char smem4[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool consumer = wave < 4;
-    const int cw = wave & 3;                 // index within the role
-    const int wm = cw & 1, wn = cw >> 1;     // consumer: channel half / pixel half
-    const int TV = T * V;
-    const int nch = C / CCB;
-    const int nstage = nch * (KT4 / STG);
-    const int img_bytes = ROWS * PXB;
-    const int buf_bytes = img_bytes * (TERMS == 3 ? 2 : 1);
-    float *W12s = reinterpret_cast<float *>(smem4);
-    char *ring = smem4 + C * W12P * 4;
-    char *buf0 = ring + 2 * STAGE_BYTES;
-    char *buf1 = buf0 + buf_bytes;
-    float4 *Fs = reinterpret_cast<float4 *>(buf1 + buf_bytes);
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem4;
-    const unsigned ring_lds = lds0 + (unsigned)(ring - smem4);
-    const unsigned fs_lds = lds0 + (unsigned)(reinterpret_cast<char *>(Fs) - smem4);
-    const int cg = blockIdx.y;
-
-    // helper hw DMAs fragments 2hw and 2hw+1 (m-block hw, hi and lo) of every tap of a stage
-    const uint4 *wsrc = Wp + ((size_t)(cg * 4 + cw) * nch * KT4 * 2) * 64 + lane;
-    auto dma_stage = [&](int gs) {
-        const unsigned dst = ring_lds + (gs & 1) * STAGE_BYTES + (2 * cw) * FRAG;
-        const int gsm = gs % nstage;
-#pragma unroll
-        for (int t = 0; t < STG; ++t) {
-            dma16(wsrc + (size_t)(gsm * STG + t) * 128, dst + t * 8 * FRAG);
-            dma16(wsrc + (size_t)(gsm * STG + t) * 128 + 64, dst + t * 8 * FRAG + FRAG);
-        }
-    };
-    auto dma_features = [&](int tile, int w0, int nw) {   // issued by waves w0 .. w0+nw-1
-        const int n = tile / tiles_per_clip;
-        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NP4);
-        const float4 *src = feat + (size_t)n * TV * 4;
-        for (int c = (wave - w0) * 64; c < 4 * ROWS; c += nw * 64) {
-            const int q = c / ROWS, j = c - q * ROWS + lane;
-            int gi = g.origin + j;
-            gi = max(0, min(gi, TV - 1));
-            dma16(src + (size_t)gi * 4 + q, fs_lds + (unsigned)(q * ROWS + (c - q * ROWS)) * 16u);
-        }
-    };
-    const int pl = lane & 15, pg = lane >> 4;
-    auto produce_block = [&](char *buf, int ch, int bi, const TileGeomB &g) {
-        const int p = bi * 16 + pl;
-        const int gi = g.origin + p;
-        const bool ok = p < g.span && gi >= 0 && gi < TV;   // outside the clip: the conv's zero padding
-        const float4 wa = *reinterpret_cast<const float4 *>(W12s + (ch * CCB + pl) * W12P + 4 * pg);
-        float4 fb = Fs[(size_t)pg * ROWS + p];
-        if (!ok) fb = make_float4(0.f, 0.f, 0.f, 0.f);
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, fb.x, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, fb.y, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, fb.z, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, fb.w, d, 0, 0, 0);
-        const float v0 = fmaxf(d[0], 0.f), v1 = fmaxf(d[1], 0.f), v2 = fmaxf(d[2], 0.f), v3 = fmaxf(d[3], 0.f);
-        const unsigned h0 = pack_bf16x2(v0, v1), h1 = pack_bf16x2(v2, v3);
-        const int off = lds_off(p, pg >> 1) + (pg & 1) * 8;
-        *reinterpret_cast<uint2 *>(buf + off) = make_uint2(h0, h1);
-        if constexpr (TERMS == 3) {
-            const unsigned l0 = pack_bf16x2(v0 - bf16_lo_to_f32(h0), v1 - bf16_hi_to_f32(h0));
-            const unsigned l1 = pack_bf16x2(v2 - bf16_lo_to_f32(h1), v3 - bf16_hi_to_f32(h1));
-            *reinterpret_cast<uint2 *>(buf + img_bytes + off) = make_uint2(l0, l1);
-        }
-    };
-
-    // ---- one-time setup ----------------------------------------------------------------------
-    for (int e = tid; e < C * W12P; e += NT4) W12s[e] = W12[e];
-    int tile = blockIdx.x;
-    if (tile < ntiles) dma_features(tile, 0, 8);
-    if (!consumer) dma_stage(0);
-    dma_wait();
-    __syncthreads();
-    if (tile < ntiles) {   // chunk 0 of the first tile: all 8 waves
-        const int n0 = tile / tiles_per_clip;
-        const TileGeomB g0 = tile_geom_b(tile - n0 * tiles_per_clip, V, KT4, 1, T, NP4);
-        const int nblk0 = (g0.span + 15) >> 4;
-        for (int b = wave; b < nblk0; b += 8) produce_block(buf0, 0, b, g0);
-    }
-    __syncthreads();
-
-    int gs = 0;
-    const int h = lane >> 5;
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int n = tile / tiles_per_clip;
-        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NP4);
-        const int nblk = (g.span + 15) >> 4;
-        const int next_tile = tile + gridDim.x;
-
-        if (consumer) {
-            // ================================ CONSUMER: fragments + MFMAs only ================================
-            int prow[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int q = g.q0 + wn * 128 + j * 32 + (lane & 31);
-                q = min(q, g.q_last);
-                const int t = q / V, v = q - t * V;
-                prow[j] = (t - g.t_first) * V + v;
-            }
-            f32x16 acc[2][4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
-
-            for (int ch = 0; ch < nch; ++ch) {
-                const char *cur = (ch & 1) ? buf1 : buf0;
-#pragma unroll
-                for (int st = 0; st < KT4 / STG; ++st, ++gs) {
-                    const char *aslot = ring + (gs & 1) * STAGE_BYTES + (wm * 4) * FRAG + lane * 16;
-#pragma unroll
-                    for (int tt = 0; tt < STG; ++tt) {
-                        const int tap = st * STG + tt;
-                        uint4 ah[2], al[2], bh[4], bl[4];
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            ah[m] = *reinterpret_cast<const uint4 *>(aslot + (tt * 8 + m * 2) * FRAG);
-                            if constexpr (TERMS == 3) al[m] = *reinterpret_cast<const uint4 *>(aslot + (tt * 8 + m * 2 + 1) * FRAG);
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int off = lds_off(prow[j] + tap * V, h);
-                            bh[j] = *reinterpret_cast<const uint4 *>(cur + off);
-                            if constexpr (TERMS == 3) bl[j] = *reinterpret_cast<const uint4 *>(cur + img_bytes + off);
-                        }
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[m]);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const bf16x8 b_h = __builtin_bit_cast(bf16x8, bh[j]);
-                                if constexpr (TERMS == 3) {
-                                    const bf16x8 a_l = __builtin_bit_cast(bf16x8, al[m]);
-                                    const bf16x8 b_l = __builtin_bit_cast(bf16x8, bl[j]);
-                                    if (!STGCN_ABL(2)) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc[m][j], 0, 0, 0);
-                                    if (!STGCN_ABL(2)) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc[m][j], 0, 0, 0);
-                                }
-                                if (!STGCN_ABL(2)) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc[m][j], 0, 0, 0);
-                            }
-                        }
-                    }
-                    __syncthreads();   // stage boundary (the helpers publish the next weight stage / chunk here)
-                }
-            }
-
-            // epilogue through this wave's 8 KiB slice of buf1 (idle now; the helpers fill buf0 meanwhile)
-            if (!STGCN_ABL(4)) {
-            float *stg = reinterpret_cast<float *>(buf1 + cw * 8192);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int ob = cg * 128 + (wm * 2 + m) * 32;
-#pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {                 // two 64-pixel halves of the wave's 128 pixels
-                    const int qw = g.q0 + wn * 128 + jp * 64;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int cr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        const float sh = shift[ob + cr];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            stg[cr * 64 + j * 32 + (lane & 31)] = fmaxf(acc[m][jp * 2 + j][r] + sh, 0.f);
-                    }
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int idx = it * 64 + lane, row = idx >> 4, c4 = (idx & 15) * 4;
-                        const float4 v = *reinterpret_cast<const float4 *>(stg + row * 64 + c4);
-                        const int q = qw + c4;
-                        const size_t gidx = ((size_t)n * C + ob + row) * TV + q;
-                        if (q + 3 <= g.q_last && (!BF16OUT || (gidx & 1) == 0)) {
-                            if constexpr (BF16OUT) {
-                                *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + gidx) =
-                                    make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-                            } else {
-                                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + gidx) = v;
-                            }
-                        } else {
-                            const float e4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (q + e <= g.q_last) store_out<BF16OUT>(y, gidx + e, e4[e]);
-                        }
-                    }
-                }
-            }
-            }
-        } else {
-            // ================================ HELPER: DMA + producer ================================
-            for (int ch = 0; ch < nch; ++ch) {
-                char *nxt = (ch & 1) ? buf0 : buf1;
-                const bool last = ch + 1 == nch;
-                if (last && next_tile < ntiles) dma_features(next_tile, 4, 4);   // Fs is idle during the last chunk
-#pragma unroll
-                for (int st = 0; st < KT4 / STG; ++st, ++gs) {
-                    if (!STGCN_ABL(64)) dma_stage(gs + 1);
-                    if (!last && !STGCN_ABL(1)) {
-#pragma unroll
-                        for (int tt = 0; tt < STG; ++tt) {
-                            const int tap = st * STG + tt;
-                            if (tap < PB) produce_block(nxt, ch + 1, min(cw + 4 * tap, nblk - 1), g);
-                        }
-                    }
-                    dma_wait();
-                    __syncthreads();
-                }
-            }
-            if (next_tile < ntiles) {   // chunk 0 of the next tile while the consumers store this one
-                const int n2 = next_tile / tiles_per_clip;
-                const TileGeomB g2 = tile_geom_b(next_tile - n2 * tiles_per_clip, V, KT4, 1, T, NP4);
-                const int nblk2 = (g2.span + 15) >> 4;
-                for (int b = cw; b < nblk2; b += 4) produce_block(buf0, 0, b, g2);
-            }
-        }
-        __syncthreads();   // tile boundary: outputs issued, chunk 0 of the next tile visible
-    }
-}
-
 struct V4Plan {
-    int pb = 0, pb5 = 0, rows = 0, tiles_per_clip = 0;
+    int pb = 0, rows = 0, tiles_per_clip = 0;
     size_t lds = 0;
 };
 
@@ -565,14 +338,13 @@ inline bool plan_v4(int C, int T, int V, int K, int terms, V4Plan &pl) {
     if (dt > T - 1) dt = T - 1;
     const int span = (dt + K) * V;
     const int rows = (span + 63) / 64 * 64;          // feature DMA moves 64 rows per wave-instruction
-    const int pb = ceil_div(ceil_div(span, 16), 8);  // producer blocks per wave per chunk (KF4: 8 producing waves)
-    const int pb5 = ceil_div(ceil_div(span, 16), 4); // KF5: 4 helper waves
+    const int pb = ceil_div(ceil_div(span, 16), 8);  // producer blocks per wave per chunk (8 producing waves)
     if (pb > KT4) return false;
     const size_t buf = (size_t)rows * PXB * (terms == 3 ? 2 : 1);
-    const size_t lds = (size_t)C * W12P * 4 + 2 * STAGE_BYTES + 2 * buf + (size_t)rows * 64;
+    const size_t img = 2 * buf > (size_t)8 * EPI_BYTES ? 2 * buf : (size_t)8 * EPI_BYTES;  // images / epilogue staging
+    const size_t lds = (size_t)C * W12P * 4 + 2 * STAGE_BYTES + img + (size_t)rows * 64;
     if (lds > (size_t)kLdsBytes) return false;
     pl.pb = pb;
-    pl.pb5 = pb5;
     pl.rows = rows;
     pl.tiles_per_clip = ceil_div(T * V, NP4);
     pl.lds = lds;
@@ -600,27 +372,6 @@ int launch_v4(const float4 *feat, const float *W12, const uint4 *Wp, const float
     return STGCN_OK;
 }
 
-template <int PB, int TERMS>
-int launch_v5(const float4 *feat, const float *W12, const uint4 *Wp, const float *shift, void *y, int N, int C, int T,
-              int V, const V4Plan &pl, bool bf16out, int num_cu, hipStream_t st) {
-    const int ntiles = N * pl.tiles_per_clip;
-    const int gx = ntiles < num_cu ? ntiles : num_cu;
-    const dim3 grid(gx, C / 128, 1);
-    if (bf16out) {
-        auto kern = stem_bf16_v5_kernel<PB, TERMS, true>;
-        STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
-        hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
-                           pl.tiles_per_clip, ntiles, ablate_mask());
-    } else {
-        auto kern = stem_bf16_v5_kernel<PB, TERMS, false>;
-        STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
-        hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
-                           pl.tiles_per_clip, ntiles, ablate_mask());
-    }
-    STGCN_LAUNCH_CHECK("stem_bf16_v5_kernel");
-    return STGCN_OK;
-}
-
 }  // namespace
 
 bool stem_v4_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags) {
@@ -645,19 +396,6 @@ int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, cons
     const float4 *f4 = (const float4 *)feat;
     const float *W12 = (const float *)prep_w12;
     const uint4 *wp = (const uint4 *)Wp;
-    // The role-specialised KF5 was measured equal to KF4 within noise (0.82-0.84 ms vs 0.80-0.83 ms on 256 clips):
-    // its consumer waves hold 128 accumulator + 48 fragment registers and cannot also double-buffer the fragments
-    // under the 256-VGPR cap, so each tap pays an LDS round trip that KF4's second wave per SIMD hides.  KF4 stays
-    // the default; STGCN_KF5=1 selects KF5 for A/B runs.
-    const char *use_v5 = getenv("STGCN_KF5");
-    if (pl.pb5 <= KT4 && use_v5 && use_v5[0] == '1') {
-#define GO5(PB)                                                                                                 \
-    return terms == 3 ? launch_v5<PB, 3>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, num_cu, st)          \
-                      : launch_v5<PB, 1>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, num_cu, st)
-        if (pl.pb5 <= 8) GO5(8);
-        GO5(9);
-#undef GO5
-    }
 #define GO(PB)                                                                                                  \
     return terms == 3 ? launch_v4<PB, 3>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, num_cu, st)          \
                       : launch_v4<PB, 1>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, num_cu, st)

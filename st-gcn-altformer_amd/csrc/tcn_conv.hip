@@ -595,7 +595,7 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
     return launch_tcn_pack(Wt, t_scale, (char *)prep + stem_w12_bytes(C), C, C, K, flags, st);
 }
 
-// workspace of the fused stem: [ P : N*S*V*V floats, 256-B aligned ][ features : N*T*V*16 floats, when used ]
+// workspace of the fused stem: [ P : N*S*V*V floats, 256-B aligned ][ features : N*T*V x 64 B (16 features as bf16 hi + lo), when used ]
 static size_t stem_ws_p_bytes(int N, int V, int S) { return align_up((size_t)N * S * V * V * sizeof(float), 256); }
 
 size_t stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {

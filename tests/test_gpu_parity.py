@@ -400,3 +400,25 @@ def test_persistent_kernel_uneven_tiles(N, dev):
     sel = [0, N // 2, N - 1]
     ref = so.stem_forward(x[sel].double(), gp.to(torch.float64), tp.to(torch.float64))
     parity_gate(fused[sel], ref, 1e-4, "clips vs oracle")
+
+
+@pytest.mark.parametrize("math,N,T,V", [("bf16", 40, 180, 22), ("bf16x3", 80, 300, 7), ("bf16x3", 48, 90, 25),
+                                        ("bf16", 80, 300, 7)])
+def test_persistent_kernel_many_tiles_small_images(math, N, T, V, dev):
+    """Every workgroup of the persistent kernel runs several tiles at shapes whose LDS image buffers are smaller
+    than at the BASELINE shape (narrow V, or one image per buffer in bf16 mode): the epilogue staging and the
+    prefetched feature tile of the next tile must not overlap."""
+    from stgcn_amd import enable_stem_fusion, set_math_mode
+    from oracle import stgcn_oracle as so
+    gcn, tcn, gp, tp, gen = _random_stem(V, None, 500 + N + V, dev)
+    set_math_mode(tcn, math)
+    x = torch.randn(N, 3, T, V, generator=gen)
+    with torch.no_grad():
+        two = tcn(gcn(x.to(dev)))
+        enable_stem_fusion(gcn, tcn)
+        fused = tcn(gcn(x.to(dev)))
+    gate, strict = MATH_GATES[math]
+    parity_gate(fused, two, 2 * gate, "fused vs two-stage", strict=False)
+    sel = [0, 1, N // 2, N - 2, N - 1]
+    ref = so.stem_forward(x[sel].double(), gp.to(torch.float64), tp.to(torch.float64))
+    parity_gate(fused[sel], ref, gate, "clips vs oracle", strict=strict)

@@ -90,5 +90,22 @@ __device__ __forceinline__ void mfma_kstep_bf16(f32x16 (&acc)[2][2], const Frag2
 }
 
 
+// the 6 (or 2) MFMAs of channel block m of one k-step (one half of mfma_kstep_bf16)
+template <int TERMS>
+__device__ __forceinline__ void mfma_half_bf16(f32x16 (&acc)[2][2], const Frag2<TERMS> &a, const Frag2<TERMS> &b, int m) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a.hi[m]);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi[n]);
+        if constexpr (TERMS == 3) {
+            const bf16x8 al = __builtin_bit_cast(bf16x8, a.lo[m]);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, b.lo[n]);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m][n], 0, 0, 0);
+        }
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m][n], 0, 0, 0);
+    }
+}
+
 }  // namespace bf16k
 }  // namespace stgcn

@@ -135,23 +135,35 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     // Then ReLU, hi/lo split and two 8-byte LDS stores.  (Spreading the MFMAs between the consumer MFMAs and
     // finishing a tap later was measured 3 % slower: more live registers, same pipe time.)
     const int pl = lane & 15, pg = lane >> 4;
-    auto produce_block = [&](char *buf, int ch, int bi) {
-        const int p = bi * 16 + pl;
-        const uint4 wh = W12q[(size_t)(pg & 1) * C + ch * CCB + pl];
-        const uint4 wl = W12q[(size_t)(2 + (pg & 1)) * C + ch * CCB + pl];
-        const uint4 fb = Fs[(size_t)pg * ROWS + p];
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, fb), d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wl), __builtin_bit_cast(bf16x8, fb), d, 0, 0, 0);
-        const float v0 = fmaxf(d[0], 0.f), v1 = fmaxf(d[1], 0.f), v2 = fmaxf(d[2], 0.f), v3 = fmaxf(d[3], 0.f);
+    struct Prod { uint4 wh, wl, fb; f32x4 d; int p; };
+    auto prod_load = [&](Prod &pr, int ch, int bi) {
+        pr.p = bi * 16 + pl;
+        pr.wh = W12q[(size_t)(pg & 1) * C + ch * CCB + pl];
+        pr.wl = W12q[(size_t)(2 + (pg & 1)) * C + ch * CCB + pl];
+        pr.fb = Fs[(size_t)pg * ROWS + pr.p];
+    };
+    auto prod_mfma = [&](Prod &pr) {
+        const bf16x8 f = __builtin_bit_cast(bf16x8, pr.fb);
+        pr.d = f32x4{0.f, 0.f, 0.f, 0.f};
+        pr.d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pr.wh), f, pr.d, 0, 0, 0);
+        pr.d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pr.wl), f, pr.d, 0, 0, 0);
+    };
+    auto prod_finish = [&](char *buf, const Prod &pr) {
+        const float v0 = fmaxf(pr.d[0], 0.f), v1 = fmaxf(pr.d[1], 0.f), v2 = fmaxf(pr.d[2], 0.f), v3 = fmaxf(pr.d[3], 0.f);
         const unsigned h0 = pack_bf16x2(v0, v1), h1 = pack_bf16x2(v2, v3);
-        const int off = lds_off(p, pg >> 1) + (pg & 1) * 8;
+        const int off = lds_off(pr.p, pg >> 1) + (pg & 1) * 8;
         *reinterpret_cast<uint2 *>(buf + off) = make_uint2(h0, h1);
         if constexpr (TERMS == 3) {
             const unsigned l0 = pack_bf16x2(v0 - bf16_lo_to_f32(h0), v1 - bf16_hi_to_f32(h0));
             const unsigned l1 = pack_bf16x2(v2 - bf16_lo_to_f32(h1), v3 - bf16_hi_to_f32(h1));
             *reinterpret_cast<uint2 *>(buf + img_bytes + off) = make_uint2(l0, l1);
         }
+    };
+    auto produce_block = [&](char *buf, int ch, int bi) {  // un-pipelined form (chunk 0 of a tile)
+        Prod pr;
+        prod_load(pr, ch, bi);
+        prod_mfma(pr);
+        prod_finish(buf, pr);
     };
     // ---- one-time setup ----------------------------------------------------------------------
     for (int e = tid; e < C * 2; e += NT4) {  // W12 -> bf16 hi/lo, planes [hi k0-7][hi k8-15][lo k0-7][lo k8-15] of [C] x 16 B
@@ -229,16 +241,20 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             }
         };
 
+        // Software pipeline: the fragments of tap t+1 are fetched before the MFMAs of tap t are issued.  The activation
+        // fragments also cross the stage barriers (the chunk image is stable for the whole chunk); the weight
+        // fragments of a new stage can only be read after the barrier that publishes its DMA.
+        // (Measured neutral-to-negative, kept out: running waves 4-7 one tap out of phase with their SIMD partners
+        //  0-3 — stage barrier in front of the last tap's MFMAs — 2 % slower; the same for all 8 waves 2 % slower;
+        //  other producer/DMA taps for waves 4-7 and a static s_setprio for that half: neutral.  The kernel is
+        //  clock-limited under load — tools/power_probe.py: 17 % faster on zero operands, same instruction stream —
+        //  so removed stalls come back partly as a lower clock.)
+        Frag2<TERMS> a_cur = {}, b_cur = {}, a_nxt = {}, b_nxt = {};
         for (int ch = 0; ch < nch; ++ch) {
             const char *cur = (ch & 1) ? buf1 : buf0;
             char *nxt = (ch & 1) ? buf0 : buf1;
             const bool last = ch + 1 == nch;
             if (last && next_tile < ntiles) dma_features(next_tile);   // Fs is idle during the last chunk
-            // Software pipeline: the fragments of tap t+1 are fetched before the MFMAs of tap t are issued (hipcc
-            // otherwise reads right in front of each use and every tap pays an LDS round trip).  The activation
-            // fragments also cross the stage barriers (the chunk image is stable for the whole chunk); the weight
-            // fragments of a new stage can only be read after the barrier that publishes its DMA.
-            Frag2<TERMS> a_cur = {}, b_cur = {}, a_nxt = {}, b_nxt = {};
             load_b(b_cur, cur, 0);
 #pragma unroll
             for (int st = 0; st < KT4 / STG; ++st, ++gs) {
@@ -248,18 +264,27 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
 #pragma unroll
                 for (int tt = 0; tt < STG; ++tt) {
                     const int tap = st * STG + tt;
+                    // Hard scheduling fences (sched_barrier(0)): left to itself hipcc sinks the fragment reads of
+                    // tap t+1 below the MFMAs of tap t and waits for them right in front of their first use, and
+                    // does the same with the producer's operands.  Phases of a tap:
+                    //   reads (producer operands first, then the next tap's fragments) | 6 MFMAs | producer MFMAs +
+                    //   weight DMA | 6 MFMAs | producer ReLU / split / stores
+                    const bool prod = tap < PB && !last && !STGCN_ABL(1);
+                    Prod pr = {};
+                    if (prod) prod_load(pr, ch + 1, min(wave + 8 * tap, nblk - 1));
                     if (tt + 1 < STG) load_a(a_nxt, aslot, tt + 1);
                     if (tap + 1 < KT4) load_b(b_nxt, cur, tap + 1);
-                    if (!STGCN_ABL(2)) mfma_kstep_bf16<TERMS>(acc, a_cur, b_cur);
-                    __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 8 : 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, TERMS == 3 ? 12 : 4, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!STGCN_ABL(2)) mfma_half_bf16<TERMS>(acc, a_cur, b_cur, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (prod) prod_mfma(pr);
                     // next weight stage -> other ring slot (its readers passed the last barrier); issued behind the
-                    // first tap's MFMAs so the DMA's issue cost does not delay the start of the stage
+                    // first MFMAs so the DMA's issue cost does not delay the start of the stage
                     if (tt == 0) dma_stage(gs + 1);
-                    // (Giving waves 4-7 their producer blocks / DMA at other taps than waves 0-3, and a static s_setprio
-                    //  for that half, were both measured neutral-to-negative.)
-                    if (tap < PB && !STGCN_ABL(1))  // (last chunk: recomputes chunk nch-1 into the idle buffer; discarded)
-                        produce_block(nxt, min(ch + 1, nch - 1), min(wave + 8 * tap, nblk - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!STGCN_ABL(2)) mfma_half_bf16<TERMS>(acc, a_cur, b_cur, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (prod) prod_finish(nxt, pr);
                     a_cur = a_nxt;
                     b_cur = b_nxt;
                 }

@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--graph", choices=["SHRE", "LMDHG"], default="SHRE")
     ap.add_argument("--math", choices=["f32", "bf16x3", "bf16", "f32_valu"], default=os.environ.get("STGCN_MATH", "bf16x3"))
     ap.add_argument("--no-fuse", action="store_true", help="two-stage path (intermediate through HBM)")
+    ap.add_argument("--layout", choices=["nctv", "ntvc"], default="nctv",
+                    help="nctv = the reference's call (contiguous (N,3,T,V) in, (N,C,T,V) out; the headline); ntvc = SURVEY "
+                         "§8(f)-1 layout fusion: the loader's (N,T,V,3) batch read in place, (N,T,V,C) written")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=32)
     args = ap.parse_args()
@@ -148,6 +151,9 @@ def main():
     if not args.no_fuse:
         stgcn_amd.enable_stem_fusion(gcn, tcn)
     x = synthetic_clips(n_local, T, V, seed=rank).to(dev)        # this rank's shard, resident in HBM before timing
+    if args.layout == "ntvc":
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)   # (N,T,V,3) in memory, viewed (N,3,T,V)
+        stgcn_amd.set_output_layout(tcn, "channels_last")
     stats = None
 
     def step():
@@ -215,7 +221,7 @@ def main():
             "config": {"workload": f"SHREC'17-shape stem forward: V={V}, T={T}, {n_local} clips/GPU "
                                    f"(BASELINE configs[1] batch at 1 GPU; weak-scaled)",
                        "clips_per_gpu": n_local, "global_clips": n_local * world, "T": T, "V": V,
-                       "math": args.math, "fused": not args.no_fuse, "parallelism": f"dp{world}",
+                       "math": args.math, "fused": not args.no_fuse, "layout": args.layout, "parallelism": f"dp{world}",
                        "parity": "1e-4 rel fp32 vs CPU oracle (tests/test_gpu_parity.py)"},
             "hbm_frac": round(value / world * bytes_clip / HBM_PEAK, 5),
             "mfma_frac": round(value / world * flops_clip / MFMA_PEAK[args.math], 4),

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STGCN_ABI_VERSION 2
+#define STGCN_ABI_VERSION 3
 
 typedef enum {
     STGCN_OK = 0,
@@ -55,6 +55,13 @@ typedef enum {
 #define STGCN_MATH_MASK 0xFu
 #define STGCN_OUT_BF16 0x10u
 #define STGCN_RAW 0x20u /* stgcn_tcn_*: store scale-folded conv + shift WITHOUT the ReLU (pre-activation) */
+/* Layout fusion with the callers either side of the stem (stgcn_stem_* entry points only):
+ *   STGCN_IN_NTVC : x is (N,T,V,Cin), the layout the data loader delivers — replaces the permute + contiguous copy
+ *                   at model/AltFormer/ST_GCN_AltFormer.py:62-68;
+ *   STGCN_OUT_NTVC: out is (N,T,V,C), channels last — `rearrange 'b c f p -> (b f) p c'` (model_ST.py:152) and
+ *                   `'b c f p -> (b p) f c'` (model_TS.py:161) then are views, not copies. */
+#define STGCN_IN_NTVC 0x40u
+#define STGCN_OUT_NTVC 0x80u
 
 int stgcn_version(void);
 const char *stgcn_last_error(void);
@@ -128,7 +135,7 @@ int stgcn_stem_prepare(const float *Wd, const float *bd, const float *Wdown, con
                        int Cin, int C, int K, int subsets, unsigned flags, void *stream);
 /* Workspace of the fused stem (caller-provided, stgcn_stem_ws_bytes bytes): the attention matrices
  * P (N,S,V,V) at offset 0 (valid on return) followed by per-pixel graph-conv features for the kernels
- * that consume them. */
+ * that consume them, or (STGCN_IN_NTVC on the other kernels) a channel-major copy of x. */
 size_t stgcn_stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int subsets, unsigned flags);
 /* 1 when the large-tile persistent kernel (which reads the feature part of the workspace) serves the shape */
 int stgcn_stem_features_used(int Cin, int C, int T, int V, int K, int subsets, unsigned flags);

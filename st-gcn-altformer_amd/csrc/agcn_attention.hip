@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
     const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
     float *__restrict__ P, float *__restrict__ feat, int Cin, int T, int V, int inter_c, int S, int TC,
-    int Rp, int feat_slice_off, unsigned long long *dbg) {
+    int Rp, int feat_slice_off, int xsc, int xsp, float *__restrict__ xcopy, unsigned long long *dbg) {
+    // x element (channel k, pixel p) of a clip sits at k*xsc + p*xsp: (T*V, 1) for (N,Cin,T,V), (1, Cin) for (N,T,V,Cin).
+    // xcopy (optional): channel-major copy of x for kernels downstream that read it in that layout.
 #ifdef STGCN_ABLATION  // in-kernel cycle stamps (diagnostic builds only)
 #define K1_STAMP(i) if (dbg && threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dbg[1024 + (i)] = t_; }
 #else
@@ -134,10 +136,13 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
             const int stepT = NTH / V, stepV = NTH - stepT * V;
             const int tt0 = tid / V, v0 = tid - tt0 * V;
             for (int k = 0; k < Cin; ++k) {
-                const float *xk = xn + ((size_t)k * T + t0) * V;
+                const float *xk = xn + (size_t)k * xsc + (size_t)t0 * V * xsp;
+                float *ck = xcopy ? xcopy + ((size_t)n * Cin + k) * T * V + (size_t)t0 * V : nullptr;
                 int tt = tt0, v = v0;
                 for (int e = tid; e < TC * V; e += NTH) {
-                    U[tt * Rp + k * V + v] = (tt < tc) ? xk[e] : 0.f;
+                    const float xv = (tt < tc) ? xk[(size_t)e * xsp] : 0.f;
+                    U[tt * Rp + k * V + v] = xv;
+                    if (ck && tt < tc) ck[e] = xv;
                     tt += stepT;
                     v += stepV;
                     if (v >= V) { v -= V; ++tt; }
@@ -225,8 +230,8 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
         const int px = tcf * V;
         __syncthreads();  // P complete in Sm / previous chunk consumed
         for (int k = 0; k < 3; ++k) {
-            const float *xk = xn + ((size_t)k * T + t0) * V;
-            for (int e = tid; e < px; e += NTH) Xf[k * px + e] = xk[e];
+            const float *xk = xn + (size_t)k * xsc + (size_t)t0 * V * xsp;
+            for (int e = tid; e < px; e += NTH) Xf[k * px + e] = xk[(size_t)e * xsp];
         }
         __syncthreads();
         for (int p0 = (tid & ~63); p0 < px; p0 += NTH) {   // 64 consecutive pixels per wave
@@ -275,7 +280,8 @@ template <int MAXIT>
 __global__ __launch_bounds__(256) void attention_generic_kernel(
     const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
     const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
-    float *__restrict__ P, int Cin, int T, int V, int inter_c, int S, int TC) {
+    float *__restrict__ P, int Cin, int T, int V, int inter_c, int S, int TC, int xsc, int xsp,
+    float *__restrict__ xcopy) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int s = blockIdx.x, n = blockIdx.y;
@@ -303,7 +309,9 @@ __global__ __launch_bounds__(256) void attention_generic_kernel(
         __syncthreads();
         for (int e = tid; e < Cin * px; e += 256) {
             const int k = e / px, p = e - k * px;
-            Xs[k * PXC + p] = xn[((size_t)k * T + t0) * V + p];
+            const float xv = xn[(size_t)k * xsc + ((size_t)t0 * V + p) * xsp];
+            Xs[k * PXC + p] = xv;
+            if (xcopy && s == 0) xcopy[((size_t)n * Cin + k) * T * V + (size_t)t0 * V + p] = xv;
         }
         __syncthreads();
         for (int e = tid; e < inter_c * px; e += 256) {
@@ -388,7 +396,8 @@ bool attention_emits_features(int Cin, int V, int S) {
 
 int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
                      const float *Wb, const float *bb, float *P, float *feat, int N, int Cin, int T, int V,
-                     int inter_c, int S, hipStream_t st) {
+                     int inter_c, int S, hipStream_t st, bool x_ntvc, float *xcopy) {
+    const int xsc = x_ntvc ? 1 : T * V, xsp = x_ntvc ? Cin : 1;
     if (feat != nullptr && (Cin != 3 || S != 3))
         return fail(STGCN_ERR_UNSUPPORTED, "attention: the feature pass covers Cin=3, 3 subsets (got %d, %d)", Cin, S);
     const FoldedPlan pl = plan_folded(Cin, T, V, inter_c, S, feat != nullptr);
@@ -401,7 +410,7 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
     do {                                                                                               \
         STGCN_HIP_CHECK(allow_lds((attention_folded_kernel<MI, TSL>), lds));                           \
         hipLaunchKernelGGL((attention_folded_kernel<MI, TSL>), dim3(N), dim3(256 * TSL), lds, st, x, A_eff, \
-                           Wa, ba, Wb, bb, P, feat, Cin, T, V, inter_c, S, TC, Rp, slice_off, debug_buffer()); \
+                           Wa, ba, Wb, bb, P, feat, Cin, T, V, inter_c, S, TC, Rp, slice_off, xsc, xsp, xcopy, debug_buffer()); \
     } while (0)
         if (pl.maxit <= 1) LAUNCH_FOLDED(1, 4);
         else if (pl.maxit <= 2) LAUNCH_FOLDED(2, 4);
@@ -428,7 +437,7 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
     do {                                                                                         \
         STGCN_HIP_CHECK(allow_lds(attention_generic_kernel<MI>, lds));                           \
         hipLaunchKernelGGL(attention_generic_kernel<MI>, dim3(S, N), dim3(256), lds, st, x, A_eff, \
-                           Wa, ba, Wb, bb, P, Cin, T, V, inter_c, S, TC);                        \
+                           Wa, ba, Wb, bb, P, Cin, T, V, inter_c, S, TC, xsc, xsp, xcopy);     \
     } while (0)
     if (maxit <= 2) LAUNCH_GENERIC(2);
     else if (maxit <= 4) LAUNCH_GENERIC(4);

@@ -218,7 +218,8 @@ int stgcn_stem_attention(const float *x, const float *A_eff, const float *Wa, co
     if (ws_bytes < need) return fail(STGCN_ERR_WORKSPACE, "stem: workspace %zu B < %zu B", ws_bytes, need);
     return launch_attention(x, A_eff, Wa, ba, Wb, bb, (float *)ws,
                             stem_ws_features(ws, N, Cin, C, T, V, K, subsets, flags), N, Cin, T, V, inter_c, subsets,
-                            (hipStream_t)stream);
+                            (hipStream_t)stream, (flags & STGCN_IN_NTVC) != 0,
+                            stem_ws_xcopy(ws, N, Cin, C, T, V, K, subsets, flags));
 }
 
 int stgcn_stem_tail_prepared(const float *x, const void *ws, size_t ws_bytes, const void *prep, const float *t_shift,
@@ -229,6 +230,7 @@ int stgcn_stem_tail_prepared(const float *x, const void *ws, size_t ws_bytes, co
     REQUIRE_POS(K);
     const size_t need = stem_ws_bytes(N, Cin, C, T, V, K, subsets, flags);
     if (ws_bytes < need) return fail(STGCN_ERR_WORKSPACE, "stem: workspace %zu B < %zu B", ws_bytes, need);
+    if (const float *xc = stem_ws_xcopy(const_cast<void *>(ws), N, Cin, C, T, V, K, subsets, flags)) x = xc;  // (N,T,V,Cin) input
     return launch_stem(x, (const float *)ws, stem_ws_features(const_cast<void *>(ws), N, Cin, C, T, V, K, subsets, flags),
                        prep, t_shift, out, N, Cin, C, T, V, subsets, K, flags, (hipStream_t)stream);
 }

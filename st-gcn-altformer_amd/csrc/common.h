@@ -33,6 +33,9 @@ int fail(stgcn_status st, const char *fmt, ...);
     } while (0)
 
 // phases switched off by a diagnostic build (see tcn_conv.hip); always 0 in the shipped library
+// kernel option bits that travel in the high half of the kernels' `abl` argument (the low half is the ablation mask)
+constexpr int OPT_OUT_NTVC = 1 << 16;  // store the output as (N,T,V,C) instead of (N,C,T,V)
+
 static inline int ablate_mask() {
 #ifdef STGCN_ABLATION
     const char *e = getenv("STGCN_ABLATE");
@@ -70,7 +73,7 @@ int launch_bn_fold(const float *w, const float *b, const float *rm, const float 
 
 int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
                      const float *Wb, const float *bb, float *P, float *feat, int N, int Cin, int T,
-                     int V, int inter_c, int S, hipStream_t st);
+                     int V, int inter_c, int S, hipStream_t st, bool x_ntvc = false, float *xcopy = nullptr);
 
 int launch_agcn_expand(const float *x, const float *P, const float *Wd, const float *bd,
                        const float *Wdown, const float *bdown, const float *bn_scale,
@@ -99,7 +102,7 @@ bool stem_fused_supported(int Cin, int C, int T, int V, int K, int S, unsigned f
 bool attention_emits_features(int Cin, int V, int S);
 bool stem_v4_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags);
 int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, const float *shift, void *out, int N,
-                   int C, int T, int V, int K, unsigned flags, hipStream_t st);
+                   int C, int T, int V, int K, unsigned flags, hipStream_t st);  // honours STGCN_OUT_NTVC
 
 // training-mode BatchNorm helpers (train_bn.hip)
 int launch_bn_batch_stats(const float *z, double *sums, int N, int C, size_t plane, hipStream_t st);
@@ -117,6 +120,7 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
                         int Cin, int C, int K, int S, unsigned flags, hipStream_t st);
 size_t stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int S, unsigned flags);
 float *stem_ws_features(void *ws, int N, int Cin, int C, int T, int V, int K, int S, unsigned flags);  // NULL if unused
+float *stem_ws_xcopy(void *ws, int N, int Cin, int C, int T, int V, int K, int S, unsigned flags);     // NULL if unused
 int launch_stem(const float *x, const float *P, const float *feat, const void *prep, const float *t_shift,
                 void *out, int N, int Cin, int C, int T, int V, int S, int K, unsigned flags, hipStream_t st);
 

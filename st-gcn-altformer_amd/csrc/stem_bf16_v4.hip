@@ -302,7 +302,43 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         // block through this wave's 8 KiB slice of the (now idle) image buffers and store 16 B per lane, so one
         // wave-instruction writes four 256-B channel rows.
         STGCN_STAMP(t_e0)
-        if (!STGCN_ABL(4)) {
+        if (!STGCN_ABL(4) && (abl & OPT_OUT_NTVC)) {
+            // (N,T,V,C) output: the block is staged pixel-major ([64 pixels][32 channels], 16-byte slots XOR-swizzled by
+            // the pixel so the b128 accesses are conflict-free); a wave-instruction then writes 8 pixels x 128 B.
+            float *stg = reinterpret_cast<float *>(buf0 + wave * EPI_BYTES);
+            const int qw = g.q0 + wn * 64;
+            const int hh = lane >> 5;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int ob = cg * 128 + (wm * 2 + m) * 32;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 sh4 = *reinterpret_cast<const float4 *>(shift + ob + 8 * gq + 4 * hh);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int px = j * 32 + (lane & 31);
+                        const float4 v = make_float4(fmaxf(acc[m][j][4 * gq + 0] + sh4.x, 0.f), fmaxf(acc[m][j][4 * gq + 1] + sh4.y, 0.f),
+                                                     fmaxf(acc[m][j][4 * gq + 2] + sh4.z, 0.f), fmaxf(acc[m][j][4 * gq + 3] + sh4.w, 0.f));
+                        *reinterpret_cast<float4 *>(stg + px * 32 + (((2 * gq + hh) ^ (px & 7)) << 2)) = v;
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int idx = it * 64 + lane, px = idx >> 3, sl = idx & 7;
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + px * 32 + ((sl ^ (px & 7)) << 2));
+                    const int q = qw + px;
+                    const size_t gidx = ((size_t)n * TV + q) * C + ob + 4 * sl;
+                    if (q <= g.q_last) {
+                        if constexpr (BF16OUT) {
+                            *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + gidx) =
+                                make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                        } else {
+                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + gidx) = v;
+                        }
+                    }
+                }
+            }
+        } else if (!STGCN_ABL(4)) {
             float *stg = reinterpret_cast<float *>(buf0 + wave * EPI_BYTES);
             const int qw = g.q0 + wn * 64;                       // first pixel of this wave's 64 columns
 #pragma unroll
@@ -378,7 +414,7 @@ inline bool plan_v4(int C, int T, int V, int K, int terms, V4Plan &pl) {
 
 template <int PB, int TERMS>
 int launch_v4(const float4 *feat, const float *W12, const uint4 *Wp, const float *shift, void *y, int N, int C, int T,
-              int V, const V4Plan &pl, bool bf16out, int num_cu, hipStream_t st) {
+              int V, const V4Plan &pl, bool bf16out, int opt, int num_cu, hipStream_t st) {
     const int ntiles = N * pl.tiles_per_clip;
     const int gx = ntiles < num_cu ? ntiles : num_cu;
     const dim3 grid(gx, C / 128, 1);
@@ -386,12 +422,12 @@ int launch_v4(const float4 *feat, const float *W12, const uint4 *Wp, const float
         auto kern = stem_bf16_v4_kernel<PB, TERMS, true>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
-                           pl.tiles_per_clip, ntiles, ablate_mask(), debug_buffer());
+                           pl.tiles_per_clip, ntiles, ablate_mask() | opt, debug_buffer());
     } else {
         auto kern = stem_bf16_v4_kernel<PB, TERMS, false>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
-                           pl.tiles_per_clip, ntiles, ablate_mask(), debug_buffer());
+                           pl.tiles_per_clip, ntiles, ablate_mask() | opt, debug_buffer());
     }
     STGCN_LAUNCH_CHECK("stem_bf16_v4_kernel");
     return STGCN_OK;
@@ -412,6 +448,7 @@ int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, cons
     const unsigned math = flags & STGCN_MATH_MASK;
     const int terms = math == STGCN_MATH_BF16X3 ? 3 : 1;
     const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
+    const int opt = (flags & STGCN_OUT_NTVC) ? OPT_OUT_NTVC : 0;
     V4Plan pl;
     if (!plan_v4(C, T, V, K, terms, pl))
         return fail(STGCN_ERR_UNSUPPORTED, "stem v4 kernel does not cover C=%d T=%d V=%d K=%d", C, T, V, K);
@@ -422,8 +459,8 @@ int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, cons
     const float *W12 = (const float *)prep_w12;
     const uint4 *wp = (const uint4 *)Wp;
 #define GO(PB)                                                                                                  \
-    return terms == 3 ? launch_v4<PB, 3>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, num_cu, st)          \
-                      : launch_v4<PB, 1>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, num_cu, st)
+    return terms == 3 ? launch_v4<PB, 3>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, opt, num_cu, st)     \
+                      : launch_v4<PB, 1>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, opt, num_cu, st)
     if (pl.pb <= 4) GO(4);
     if (pl.pb <= 6) GO(6);
     GO(9);

@@ -474,7 +474,8 @@ __global__ __launch_bounds__(NT) void stem_mfma_bf16_kernel(
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
-                if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[m][j][r] + sh, 0.f));
+                const size_t idx = (abl & OPT_OUT_NTVC) ? ((size_t)n * TV + q) * C + o : base + q;  // (N,T,V,C) | (N,C,T,V)
+                if (q <= g.q_last) store_out<BF16OUT>(y, idx, fmaxf(acc[m][j][r] + sh, 0.f));
             }
         }
     }
@@ -507,16 +508,16 @@ inline bool plan_stem_bf16(int C, int V, int K, int T, int terms, StemPlan &pl) 
 
 template <int PB, int TERMS, int KT>
 int launch_stem_variant(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y,
-                        int N, int C, int T, int V, int K, const StemPlan &pl, bool bf16out, hipStream_t st) {
+                        int N, int C, int T, int V, int K, const StemPlan &pl, bool bf16out, int opt, hipStream_t st) {
     const dim3 grid(ceil_div(T * V, NPB), C / 128, N);
     if (bf16out) {
         auto kern = stem_mfma_bf16_kernel<PB, TERMS, true, KT>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
-        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, C, T, V, K, pl.rows, ablate_mask());
+        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, C, T, V, K, pl.rows, ablate_mask() | opt);
     } else {
         auto kern = stem_mfma_bf16_kernel<PB, TERMS, false, KT>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
-        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, C, T, V, K, pl.rows, ablate_mask());
+        hipLaunchKernelGGL(kern, grid, dim3(NT), pl.lds, st, x, P, W12, Wp, shift, y, C, T, V, K, pl.rows, ablate_mask() | opt);
     }
     STGCN_LAUNCH_CHECK("stem_mfma_bf16_kernel");
     return STGCN_OK;
@@ -524,8 +525,8 @@ int launch_stem_variant(const float *x, const float *P, const float *W12, const 
 
 template <int TERMS>
 int dispatch_stem(const float *x, const float *P, const float *W12, const uint4 *Wp, const float *shift, void *y, int N,
-                  int C, int T, int V, int K, const StemPlan &pl, bool bf16out, hipStream_t st) {
-#define GO(PB, KT) return launch_stem_variant<PB, TERMS, KT>(x, P, W12, Wp, shift, y, N, C, T, V, K, pl, bf16out, st)
+                  int C, int T, int V, int K, const StemPlan &pl, bool bf16out, int opt, hipStream_t st) {
+#define GO(PB, KT) return launch_stem_variant<PB, TERMS, KT>(x, P, W12, Wp, shift, y, N, C, T, V, K, pl, bf16out, opt, st)
     if (K == 9) {
         if (pl.pb <= 3) GO(3, 9);
         if (pl.pb <= 6) GO(6, 9);
@@ -635,8 +636,9 @@ int launch_tcn_bf16(const float *x, const float *P, const float *W12, const void
         StemPlan sp;
         if (Cin != Cout || stride != 1 || !plan_stem_bf16(Cin, V, K, T, terms, sp))
             return fail(STGCN_ERR_UNSUPPORTED, "fused bf16 stem kernel does not cover C=%d V=%d K=%d T=%d", Cin, V, K, T);
-        if (terms == 3) return dispatch_stem<3>(x, P, W12, (const uint4 *)Wp, shift, y, N, Cin, T, V, K, sp, bf16out, st);
-        return dispatch_stem<1>(x, P, W12, (const uint4 *)Wp, shift, y, N, Cin, T, V, K, sp, bf16out, st);
+        const int opt = (flags & STGCN_OUT_NTVC) ? OPT_OUT_NTVC : 0;
+        if (terms == 3) return dispatch_stem<3>(x, P, W12, (const uint4 *)Wp, shift, y, N, Cin, T, V, K, sp, bf16out, opt, st);
+        return dispatch_stem<1>(x, P, W12, (const uint4 *)Wp, shift, y, N, Cin, T, V, K, sp, bf16out, opt, st);
     }
     Bf16Plan pl;
     if (Tout < 1 || !plan_bf16(Cin, Cout, V, K, stride, Tout, terms, pl))

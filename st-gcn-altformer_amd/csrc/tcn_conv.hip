@@ -199,7 +199,8 @@ __device__ __forceinline__ void mfma_tap(f32x16 (&acc)[4], float4 a0, float4 a1,
 template <bool BF16OUT>
 __device__ __forceinline__ void epilogue_store(const f32x16 (&acc)[4], const TileGeom &g,
                                                const float *__restrict__ shift, void *y, int n, int Cout,
-                                               int mb, int lane, int pixels_per_clip, float lo = 0.f) {
+                                               int mb, int lane, int pixels_per_clip, float lo = 0.f,
+                                               bool ntvc = false /* (N,T,V,C) output */) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int o = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -208,7 +209,8 @@ __device__ __forceinline__ void epilogue_store(const f32x16 (&acc)[4], const Til
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int q = g.q0 + j * 32 + (lane & 31);
-            if (q <= g.q_last) store_out<BF16OUT>(y, base + q, fmaxf(acc[j][r] + sh, lo));
+            const size_t idx = ntvc ? ((size_t)n * pixels_per_clip + q) * Cout + o : base + q;
+            if (q <= g.q_last) store_out<BF16OUT>(y, idx, fmaxf(acc[j][r] + sh, lo));
         }
     }
 }
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256) void stem_mfma_f32_kernel(
         }
         __syncthreads();
     }
-    if (!STGCN_ABL(4)) epilogue_store<BF16OUT>(acc, g, shift, y, n, C, mb, lane, TV);
+    if (!STGCN_ABL(4)) epilogue_store<BF16OUT>(acc, g, shift, y, n, C, mb, lane, TV, 0.f, (abl & OPT_OUT_NTVC) != 0);
 }
 
 // fold the graph-conv linear stages into W12[C][W12P] (see agcn_expand.hip for the algebra)
@@ -595,17 +597,25 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
     return launch_tcn_pack(Wt, t_scale, (char *)prep + stem_w12_bytes(C), C, C, K, flags, st);
 }
 
-// workspace of the fused stem: [ P : N*S*V*V floats, 256-B aligned ][ features : N*T*V x 64 B (16 features as bf16 hi + lo), when used ]
+// workspace of the fused stem: [ P : N*S*V*V floats, 256-B aligned ] then ONE of
+//   [ features : N*T*V x 64 B (16 features as bf16 hi + lo) ]   when the large-tile kernel serves the shape, or
+//   [ x copy   : N*Cin*T*V floats, channel-major ]              with STGCN_IN_NTVC on the kernels that read x themselves
 static size_t stem_ws_p_bytes(int N, int V, int S) { return align_up((size_t)N * S * V * V * sizeof(float), 256); }
 
 size_t stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {
     size_t b = stem_ws_p_bytes(N, V, S);
     if (stem_v4_supported(Cin, C, T, V, K, S, flags)) b += (size_t)N * T * V * 16 * sizeof(float);
+    else if (flags & STGCN_IN_NTVC) b += (size_t)N * Cin * T * V * sizeof(float);
     return b;
 }
 
 float *stem_ws_features(void *ws, int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {
     if (!stem_v4_supported(Cin, C, T, V, K, S, flags)) return nullptr;
+    return reinterpret_cast<float *>(static_cast<char *>(ws) + stem_ws_p_bytes(N, V, S));
+}
+
+float *stem_ws_xcopy(void *ws, int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {
+    if (!(flags & STGCN_IN_NTVC) || stem_v4_supported(Cin, C, T, V, K, S, flags)) return nullptr;
     return reinterpret_cast<float *>(static_cast<char *>(ws) + stem_ws_p_bytes(N, V, S));
 }
 
@@ -639,7 +649,7 @@ int launch_stem(const float *x, const float *P, const float *feat, const void *p
     do {                                                                                                \
         STGCN_HIP_CHECK(allow_lds(stem_mfma_f32_kernel<J, B>, lds));                                    \
         hipLaunchKernelGGL((stem_mfma_f32_kernel<J, B>), grid, dim3(256), lds, st, x, P, W12, Wp, t_shift, \
-                           out, C, T, V, K, ROW, ablate_mask());                                        \
+                           out, C, T, V, K, ROW, ablate_mask() | ((flags & STGCN_OUT_NTVC) ? OPT_OUT_NTVC : 0)); \
     } while (0)
     if (jpr == 1) { if (bf16out) LAUNCH_STEM(1, true); else LAUNCH_STEM(1, false); }
     else if (jpr == 2) { if (bf16out) LAUNCH_STEM(2, true); else LAUNCH_STEM(2, false); }

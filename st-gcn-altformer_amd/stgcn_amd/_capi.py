@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STGCN_LIB") or os.path.join(_HERE, "libstgcn_hip.so")   # STGCN_LIB: diagnostic builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # stgcn_math / flags (include/stgcn_hip.h)
 MATH_F32 = 0
@@ -21,6 +21,9 @@ MATH_BF16 = 2
 MATH_F32_VALU = 3
 MATH_MASK = 0xF
 OUT_BF16 = 0x10
+RAW = 0x20
+IN_NTVC = 0x40    # stem entry points: x is (N,T,V,Cin)
+OUT_NTVC = 0x80   # stem entry points: out is (N,T,V,C)
 
 STATUS = {0: "STGCN_OK", -1: "STGCN_ERR_ARG", -2: "STGCN_ERR_UNSUPPORTED",
           -3: "STGCN_ERR_WORKSPACE", -4: "STGCN_ERR_HIP"}

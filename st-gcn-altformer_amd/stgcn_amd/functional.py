@@ -171,18 +171,35 @@ def stem_prepare(Wd, bd, Wdown, bdown, bn_scale, bn_shift, down_scale, down_shif
     return prep
 
 
+def _is_channels_last(x: torch.Tensor) -> bool:
+    """(N,C,T,V)-shaped tensor whose memory is (N,T,V,C) — what ``x.permute(0,3,1,2)`` of the loader's batch is."""
+    return x.dim() == 4 and not x.is_contiguous() and x.permute(0, 2, 3, 1).is_contiguous()
+
+
 def stem_forward(x, A_eff, Wa, ba, Wb, bb, prep, t_shift, C, K, math=MATH_F32, out_bf16=False,
-                 out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
-    """Fused tcn0(gcn0(x)).  Returns (out (N,C,T,V), P (N,S,V,V) — a view of the workspace)."""
+                 out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+                 channels_last_out: bool = False):
+    """Fused tcn0(gcn0(x)).  Returns (out (N,C,T,V), P (N,S,V,V) — a view of the workspace).
+
+    x is (N,Cin,T,V), contiguous or channels-last strided (the permuted (N,T,V,Cin) batch of
+    ST_GCN_AltFormer.py:62-68 — read in place, STGCN_IN_NTVC).  With ``channels_last_out`` the result is
+    still shaped (N,C,T,V) but laid out (N,T,V,C) (STGCN_OUT_NTVC): the rearranges of model_ST.py:152 /
+    model_TS.py:161 are views of it."""
     dev = x.device
     N, Cin, T, V = x.shape
     S, inter_c, _ = Wa.shape
     odt = torch.bfloat16 if out_bf16 else torch.float32
-    if out is None:
-        out = torch.empty(N, C, T, V, device=dev, dtype=odt)
-    elif out.shape != (N, C, T, V) or out.dtype != odt or not out.is_contiguous() or out.device != dev:
-        raise ValueError("stem_forward: `out` has the wrong shape/dtype/device")
     fl = _flags(math, out_bf16)
+    if _is_channels_last(x):
+        fl |= _capi.IN_NTVC
+        x = x.permute(0, 2, 3, 1)              # the contiguous (N,T,V,Cin) tensor behind the view
+    oshape = (N, T, V, C) if channels_last_out else (N, C, T, V)
+    if channels_last_out:
+        fl |= _capi.OUT_NTVC
+    if out is None:
+        out = torch.empty(oshape, device=dev, dtype=odt)
+    elif tuple(out.shape) != oshape or out.dtype != odt or not out.is_contiguous() or out.device != dev:
+        raise ValueError("stem_forward: `out` has the wrong shape/dtype/device")
     need = _capi.lib().stgcn_stem_ws_bytes(N, Cin, C, T, V, K, S, fl)
     if ws is None or ws.numel() * ws.element_size() < need or ws.device != dev:
         ws = torch.empty((need + 3) // 4, device=dev, dtype=torch.float32)
@@ -201,6 +218,8 @@ def stem_forward(x, A_eff, Wa, ba, Wb, bb, prep, t_shift, C, K, math=MATH_F32, o
                    c_int(N), c_int(Cin), c_int(C), c_int(T), c_int(V), c_int(S), c_int(K), c_uint(fl), st)
         if timer is not None:
             timer.stop("stem_tail", dev)
+    if channels_last_out:
+        out = out.permute(0, 3, 1, 2)          # (N,C,T,V) view, torch.channels_last strides
     return out, ws[:N * S * V * V].view(N, S, V, V)
 
 

@@ -200,11 +200,10 @@ class unit_agcn(nn.Module):
             raise RuntimeError(f"unit_agcn: expected {self.in_channels} input channels, got {x.shape[1]}")
         if x.shape[3] != self.PA.shape[-1]:
             raise RuntimeError(f"unit_agcn: input has {x.shape[3]} joints, adjacency has {self.PA.shape[-1]}")
-        x = x.contiguous()
         st = self._staged(x.device)
-        if self.training:
-            return self._forward_train(x, st)
-        if self._fusable(x):
+        if not self.training and self._fusable(x):
+            if not F._is_channels_last(x):     # the permuted (N,T,V,C) batch of ST_GCN_AltFormer.py:62-68 is read in place
+                x = x.contiguous()
             t = self._fused_tcn
             ts = t._staged(x.device)
             pkey = (st["key"], ts["key"], t.math_mode)
@@ -214,10 +213,14 @@ class unit_agcn(nn.Module):
                                                  ts["scale"], t.math_mode)
                 st["stem_key"] = pkey
             out, P = F.stem_forward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["stem_prep"],
-                                    ts["shift"], self.out_channels, t.kernel_size, t.math_mode, t.out_bf16)
+                                    ts["shift"], self.out_channels, t.kernel_size, t.math_mode, t.out_bf16,
+                                    channels_last_out=t.channels_last_out)
             self.last_attention = P
             out._stgcn_fused_for = t          # Unit2D.forward recognises its own pre-computed output
             return out
+        x = x.contiguous()
+        if self.training:
+            return self._forward_train(x, st)
         y, P = F.agcn_forward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"],
                               st["Wdown"], st["bdown"], st["bn_scale"], st["bn_shift"], st["down_scale"],
                               st["down_shift"])
@@ -276,6 +279,7 @@ class Unit2D(nn.Module):
         self.stride = stride
         self.math_mode = _default_math()
         self.out_bf16 = False
+        self.channels_last_out = False       # set_output_layout(): (N,C,T,V) result laid out (N,T,V,C)
         self._cache = None
 
     def _staged(self, device):
@@ -328,6 +332,8 @@ class Unit2D(nn.Module):
                                      self.kernel_size, self.stride, mode, self.out_bf16)
         if self.dim == 3:
             y = y.transpose(2, 3).contiguous()
+        if self.channels_last_out:           # (only the fused stem writes this layout natively)
+            y = y.contiguous(memory_format=torch.channels_last)
         return y
 
 
@@ -345,6 +351,17 @@ def enable_stem_fusion(gcn: unit_agcn, tcn: Unit2D) -> None:
 
 def disable_stem_fusion(gcn: unit_agcn) -> None:
     object.__setattr__(gcn, "_fused_tcn", None)
+
+
+def set_output_layout(module: nn.Module, layout: str) -> None:
+    """'channels_last': every Unit2D below returns its (N,C,T,V) result laid out (N,T,V,C) in memory (torch.channels_last
+    strides), so `rearrange(x, 'b c f p -> (b f) p c')` (model_ST.py:152) / `'b c f p -> (b p) f c'` (model_TS.py:161)
+    are views.  The fused stem kernel writes that layout directly; 'contiguous' restores the default."""
+    if layout not in ("channels_last", "contiguous"):
+        raise ValueError(f"unknown layout {layout!r}")
+    for sub in module.modules():
+        if isinstance(sub, Unit2D):
+            sub.channels_last_out = layout == "channels_last"
 
 
 def set_math_mode(module: nn.Module, mode) -> None:

@@ -422,3 +422,55 @@ def test_persistent_kernel_many_tiles_small_images(math, N, T, V, dev):
     sel = [0, 1, N // 2, N - 2, N - 1]
     ref = so.stem_forward(x[sel].double(), gp.to(torch.float64), tp.to(torch.float64))
     parity_gate(fused[sel], ref, gate, "clips vs oracle", strict=strict)
+
+
+# ---------------------------------------------------------------------------------------
+# SURVEY §8(f) rank 1 — layout fusion with the callers either side of the stem
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("math,N,T,V", [("bf16x3", 5, 60, 22),     # large-tile persistent kernel (features path)
+                                        ("bf16x3", 40, 180, 22),   # ... several tiles per workgroup
+                                        ("bf16", 3, 33, 25),
+                                        ("bf16x3", 2, 40, 46),     # 128-pixel kernel (LMDHG graph), reads the x copy
+                                        ("f32", 3, 37, 22),        # fp32 matrix-core kernel
+                                        ("f32", 2, 20, 46)])
+@pytest.mark.parametrize("out_bf16", [False, True])
+def test_stem_layout_fusion_is_bit_exact(math, N, T, V, out_bf16, dev):
+    """STGCN_IN_NTVC / STGCN_OUT_NTVC change addressing only: reading the loader's (N,T,V,3) batch in place and
+    writing (N,T,V,C) must give the same bits as the (N,C,T,V) call (ST_GCN_AltFormer.py:62-68, model_ST.py:152)."""
+    from stgcn_amd import enable_stem_fusion, set_math_mode, set_output_layout
+    from oracle import stgcn_oracle as so
+    gcn, tcn, gp, tp, gen = _random_stem(V, None, 700 + T + V, dev)
+    set_math_mode(tcn, math)
+    tcn.out_bf16 = out_bf16
+    enable_stem_fusion(gcn, tcn)
+    batch = torch.randn(N, T, V, 3, generator=gen).to(dev)             # as the data loader delivers it
+    x_view = batch.permute(0, 3, 1, 2)                                  # ST_GCN_AltFormer.py:64 (no copy)
+    assert not x_view.is_contiguous()
+    with torch.no_grad():
+        base = tcn(gcn(x_view.contiguous()))                            # the reference's own call sequence (:68)
+        P_base = gcn.last_attention.clone()
+        z_in = tcn(gcn(x_view))                                         # permuted view read in place
+        assert torch.equal(gcn.last_attention, P_base)
+        assert torch.equal(z_in, base)
+        set_output_layout(tcn, "channels_last")
+        z_cl = tcn(gcn(x_view))
+    assert z_cl.shape == base.shape and z_cl.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(z_cl, base)
+    from einops import rearrange
+    st_tokens = rearrange(z_cl, "b c f p -> (b f) p c")                 # model_ST.py:152
+    assert st_tokens.data_ptr() == z_cl.data_ptr(), "rearrange copied: the channels-last result is not a view"
+    assert torch.equal(st_tokens, rearrange(base, "b c f p -> (b f) p c"))
+    if not out_bf16:
+        ref = so.stem_forward(x_view[:2].double().cpu(), gp.to(torch.float64), tp.to(torch.float64))
+        gate, strict = MATH_GATES[math]
+        parity_gate(z_cl[:2], ref, gate, "channels-last stem vs oracle", strict=strict)
+
+
+def test_two_stage_path_accepts_channels_last_input(dev):
+    """Outside the fused kernels the modules still take the permuted view (they copy, like the reference's .contiguous())."""
+    gcn, tcn, gp, tp, gen = _random_stem(22, None, 811, dev)
+    batch = torch.randn(2, 30, 22, 3, generator=gen).to(dev)
+    with torch.no_grad():
+        a = tcn(gcn(batch.permute(0, 3, 1, 2)))
+        b = tcn(gcn(batch.permute(0, 3, 1, 2).contiguous()))
+    assert torch.equal(a, b)

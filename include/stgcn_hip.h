@@ -174,11 +174,29 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
                              size_t ws_bytes, float *y, int N, int Cin, int Cout, int T, int V,
                              int inter_c, int subsets, void *stream);
 size_t stgcn_tcn_train_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
+/* save_z (N,Cout,T_out,V), save_mean, save_invstd (Cout): optional outputs for the backward — the raw
+ * convolution conv_t(x)+b and the batch statistics, torch's save_mean / save_invstd.  NULL: not kept. */
 int stgcn_tcn_forward_train(const float *x, const float *W, const float *conv_bias,
                             const float *bn_weight, const float *bn_bias, float *bn_running_mean,
                             float *bn_running_var, float momentum, float eps, void *ws, size_t ws_bytes,
-                            float *y, int N, int Cin, int Cout, int T, int V, int K, int stride,
-                            unsigned flags, void *stream);
+                            float *y, float *save_z, float *save_mean, float *save_invstd, int N, int Cin,
+                            int Cout, int T, int V, int K, int stride, unsigned flags, void *stream);
+
+/* ---- backward of the training-mode blocks ------------------------------
+ * What autograd derives for y = relu(BatchNorm_batch(conv_t(x) + b)) (model/net.py:47-57 under
+ * train_sttran.py:185-191) from dy (N,Cout,T_out,V):
+ *   dW (Cout,Cin,K), dbias (Cout, NULL when the conv has no bias), dgamma / dbeta (Cout) of the
+ *   BatchNorm, and dx (N,Cin,T,V; NULL when the input needs no gradient).
+ * z, save_mean, save_invstd are the tensors stgcn_tcn_forward_train saved.  The weight gradient
+ * runs on the bf16 matrix cores with the arithmetic of `flags` (BF16X3: fp32 contract) where the
+ * shape allows (stride 1, Cout%128==0, Cin%32==0, K<=9), on plain fp32 FMAs otherwise; the input
+ * gradient of a stride-1 block is the forward kernel on the flipped weights. */
+size_t stgcn_tcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
+int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, const float *bn_weight,
+                             const float *bn_bias, const float *save_mean, const float *save_invstd,
+                             const float *dy, float *dx, float *dW, float *dbias, float *dgamma,
+                             float *dbeta, void *ws, size_t ws_bytes, int N, int Cin, int Cout, int T,
+                             int V, int K, int stride, unsigned flags, void *stream);
 
 /* ---- data-parallel harness -------------------------------------------------------------------
  * Per-rank reductions that the ranks all-reduce once per step (the data-parallel form of the

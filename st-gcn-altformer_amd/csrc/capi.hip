@@ -318,8 +318,9 @@ size_t stgcn_tcn_train_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, i
 
 int stgcn_tcn_forward_train(const float *x, const float *W, const float *conv_bias, const float *bn_weight,
                             const float *bn_bias, float *bn_running_mean, float *bn_running_var, float momentum,
-                            float eps, void *ws, size_t ws_bytes, float *y, int N, int Cin, int Cout, int T, int V,
-                            int K, int stride, unsigned flags, void *stream) {
+                            float eps, void *ws, size_t ws_bytes, float *y, float *save_z, float *save_mean,
+                            float *save_invstd, int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags,
+                            void *stream) {
     REQUIRE_PTR(x); REQUIRE_PTR(W); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias); REQUIRE_PTR(bn_running_mean);
     REQUIRE_PTR(bn_running_var); REQUIRE_PTR(ws); REQUIRE_PTR(y);
     REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(Cout); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(K); REQUIRE_POS(stride);
@@ -332,7 +333,7 @@ int stgcn_tcn_forward_train(const float *x, const float *W, const float *conv_bi
     float *ones = (float *)ws, *zeros = ones + Cout, *s1 = zeros + Cout, *t1 = s1 + Cout;
     double *sums = (double *)(t1 + 3 * Cout);
     char *packed = (char *)ws + train_small_bytes(Cout);
-    float *z = (float *)(packed + tcn_packed_bytes(Cin, Cout, K, flags));
+    float *z = save_z ? save_z : (float *)(packed + tcn_packed_bytes(Cin, Cout, K, flags));   // conv_t(x) + b
     const size_t plane = (size_t)Tout * V, total = (size_t)N * Cout * plane;
     hipLaunchKernelGGL(fill_ones_zeros_kernel, dim3(ceil_div(Cout, 256)), dim3(256), 0, st, ones, zeros, Cout);
     STGCN_LAUNCH_CHECK("fill_ones_zeros_kernel");
@@ -344,9 +345,92 @@ int stgcn_tcn_forward_train(const float *x, const float *W, const float *conv_bi
     rc = launch_bn_batch_stats(z, sums, N, Cout, plane, st);
     if (rc != STGCN_OK) return rc;
     rc = launch_bn_train_finalize(sums, (double)N * plane, bn_weight, bn_bias, bn_running_mean, bn_running_var, momentum,
-                                  eps, s1, t1, Cout, st);
+                                  eps, s1, t1, Cout, st, save_mean, save_invstd);
     if (rc != STGCN_OK) return rc;
     return launch_bn_apply(z, s1, t1, nullptr, nullptr, nullptr, y, total, Cout, plane, st);
+}
+
+// ---- backward of the training-mode temporal conv block ---------------------------------------------------------
+// workspace: [sums 3C dbl][bsum 2C dbl][coef 3C][scale C][shift C][ones Cin][zeros Cin] | dz | flipped W | packed | wgrad partials
+static size_t tcn_bwd_small_bytes(int Cin, int Cout) {
+    return align_up((size_t)Cout * 5 * sizeof(double) + ((size_t)Cout * 5 + (size_t)Cin * 2) * sizeof(float), 256);
+}
+static unsigned tcn_dgrad_flags(int Cin, int Cout, int Tout, int V, int K, unsigned flags) {
+    unsigned math = flags & STGCN_MATH_MASK;   // dgrad = forward conv with Cout input and Cin output channels
+    if (math != STGCN_MATH_F32_VALU && !tcn_mfma_supported(Cout, Cin, Tout, V, K, 1, math)) math = STGCN_MATH_F32_VALU;
+    return math;
+}
+
+size_t stgcn_tcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || K <= 0 || stride <= 0) return 0;
+    const int Tout = (T + 2 * ((K - 1) / 2) - K) / stride + 1;
+    if (Tout < 1) return 0;
+    size_t b = tcn_bwd_small_bytes(Cin, Cout) + align_up((size_t)N * Cout * Tout * V * sizeof(float), 256);
+    if (stride == 1)
+        b += align_up((size_t)Cout * Cin * K * sizeof(float), 256) +
+             align_up(tcn_packed_bytes(Cout, Cin, K, tcn_dgrad_flags(Cin, Cout, Tout, V, K, flags)), 256);
+    return b + tcn_wgrad_ws_bytes(N, Cin, Cout, T, V, K, stride, flags);
+}
+
+int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, const float *bn_weight,
+                             const float *bn_bias, const float *save_mean, const float *save_invstd, const float *dy,
+                             float *dx, float *dW, float *dbias, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
+                             int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags, void *stream) {
+    REQUIRE_PTR(x); REQUIRE_PTR(W); REQUIRE_PTR(z); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias); REQUIRE_PTR(save_mean);
+    REQUIRE_PTR(save_invstd); REQUIRE_PTR(dy); REQUIRE_PTR(dW); REQUIRE_PTR(dgamma); REQUIRE_PTR(dbeta); REQUIRE_PTR(ws);
+    REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(Cout); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(K); REQUIRE_POS(stride);
+    const size_t need = stgcn_tcn_backward_ws_bytes(N, Cin, Cout, T, V, K, stride, flags);
+    if (need == 0) return fail(STGCN_ERR_ARG, "tcn_backward: T=%d K=%d stride=%d gives no output frame", T, K, stride);
+    if (ws_bytes < need) return fail(STGCN_ERR_WORKSPACE, "tcn_backward: workspace %zu B < %zu B", ws_bytes, need);
+    if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "tcn_backward: N=%d > 65535 clips per call", N);
+    hipStream_t st = (hipStream_t)stream;
+    const int Tout = (T + 2 * ((K - 1) / 2) - K) / stride + 1;
+    const size_t plane = (size_t)Tout * V;
+    double *sums = (double *)ws, *bsum = sums + 3 * Cout;
+    float *coef = (float *)(bsum + 2 * Cout), *scale = coef + 3 * Cout, *shift = scale + Cout, *ones = shift + Cout,
+          *zeros = ones + Cin;
+    char *p = (char *)ws + tcn_bwd_small_bytes(Cin, Cout);
+    float *dz = (float *)p;
+    p += align_up((size_t)N * Cout * plane * sizeof(float), 256);
+    int rc = launch_bn_scale_shift(bn_weight, bn_bias, save_mean, save_invstd, scale, shift, Cout, st);
+    if (rc != STGCN_OK) return rc;
+    rc = launch_bn_relu_bwd_stats(z, scale, shift, save_mean, save_invstd, nullptr, nullptr, nullptr, nullptr, nullptr, dy,
+                                  sums, N, Cout, plane, st);
+    if (rc != STGCN_OK) return rc;
+    rc = launch_bn_bwd_finalize(sums, 1, (double)N * plane, bn_weight, save_invstd, dgamma, dbeta, coef, Cout, st);
+    if (rc != STGCN_OK) return rc;
+    rc = launch_bn_relu_bwd_apply(z, scale, shift, save_mean, save_invstd, nullptr, nullptr, nullptr, nullptr, nullptr, dy,
+                                  coef, nullptr, dz, nullptr, dbias ? bsum : nullptr, N, Cout, plane, st);
+    if (rc != STGCN_OK) return rc;
+    if (dbias) {
+        rc = launch_doubles_to_floats(bsum, dbias, Cout, st);
+        if (rc != STGCN_OK) return rc;
+    }
+    if (dx != nullptr) {
+        if (stride == 1) {   // dx = conv_t(dz, flipped W): the forward kernels, raw output
+            float *Wf = (float *)p;
+            p += align_up((size_t)Cout * Cin * K * sizeof(float), 256);
+            const unsigned dfl = tcn_dgrad_flags(Cin, Cout, Tout, V, K, flags);
+            void *packed = p;
+            p += align_up(tcn_packed_bytes(Cout, Cin, K, dfl), 256);
+            hipLaunchKernelGGL(fill_ones_zeros_kernel, dim3(ceil_div(Cin, 256)), dim3(256), 0, st, ones, zeros, Cin);
+            STGCN_LAUNCH_CHECK("fill_ones_zeros_kernel");
+            rc = launch_weight_flip(W, Wf, Cout, Cin, K, st);
+            if (rc != STGCN_OK) return rc;
+            rc = launch_tcn_pack(Wf, ones, packed, Cout, Cin, K, dfl, st);
+            if (rc != STGCN_OK) return rc;
+            rc = launch_tcn(dz, packed, zeros, dx, N, Cout, Cin, Tout, V, K, 1, dfl | STGCN_RAW, st);
+            if (rc != STGCN_OK) return rc;
+        } else {
+            rc = launch_tcn_dgrad_valu(dz, W, dx, N, Cin, Cout, T, V, K, stride, Tout, st);
+            if (rc != STGCN_OK) return rc;
+        }
+    } else if (stride == 1) {
+        p += align_up((size_t)Cout * Cin * K * sizeof(float), 256) +
+             align_up(tcn_packed_bytes(Cout, Cin, K, tcn_dgrad_flags(Cin, Cout, Tout, V, K, flags)), 256);
+    }
+    float *part = tcn_wgrad_ws_bytes(N, Cin, Cout, T, V, K, stride, flags) ? (float *)p : nullptr;
+    return launch_tcn_wgrad(dz, x, dW, part, N, Cin, Cout, T, V, K, stride, Tout, flags, st);
 }
 
 int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int C, long plane, float n_local,

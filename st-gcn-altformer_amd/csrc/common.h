@@ -108,9 +108,31 @@ int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, cons
 int launch_bn_batch_stats(const float *z, double *sums, int N, int C, size_t plane, hipStream_t st);
 int launch_bn_train_finalize(const double *sums, double count, const float *weight, const float *bias,
                              float *running_mean, float *running_var, float momentum, float eps, float *scale,
-                             float *shift, int C, hipStream_t st);
+                             float *shift, int C, hipStream_t st, float *save_mean = nullptr,
+                             float *save_invstd = nullptr);
+int launch_bn_scale_shift(const float *weight, const float *bias, const float *mean, const float *invstd, float *scale,
+                          float *shift, int C, hipStream_t st);
 int launch_bn_apply(const float *za, const float *sa, const float *ta, const float *zb, const float *sb,
                     const float *tb, float *y, size_t total, int C, size_t plane, hipStream_t st);
+
+// backward of the training-mode blocks (tcn_backward.hip)
+int launch_bn_relu_bwd_stats(const float *za, const float *sa, const float *ta, const float *ma, const float *ia,
+                             const float *zb, const float *sb, const float *tb, const float *mb, const float *ib,
+                             const float *dy, double *sums, int N, int C, size_t plane, hipStream_t st);
+int launch_bn_bwd_finalize(const double *sums, int which, double count, const float *gamma, const float *invstd,
+                           float *dgamma, float *dbeta, float *coef, int C, hipStream_t st);
+int launch_bn_relu_bwd_apply(const float *za, const float *sa, const float *ta, const float *ma, const float *ia,
+                             const float *zb, const float *sb, const float *tb, const float *mb, const float *ib,
+                             const float *dy, const float *coefa, const float *coefb, float *dza, float *dzb, double *bsum,
+                             int N, int C, size_t plane, hipStream_t st);
+int launch_doubles_to_floats(const double *src, float *dst, int n, hipStream_t st);
+int launch_weight_flip(const float *W, float *Wf, int Cout, int Cin, int K, hipStream_t st);
+int launch_tcn_dgrad_valu(const float *dz, const float *W, float *dx, int N, int Cin, int Cout, int T, int V, int K,
+                          int stride, int Tout, hipStream_t st);
+bool tcn_wgrad_mfma_supported(int N, int Cin, int Cout, int T, int V, int K, int stride);
+size_t tcn_wgrad_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
+int launch_tcn_wgrad(const float *dz, const float *x, float *dW, float *part, int N, int Cin, int Cout, int T, int V, int K,
+                     int stride, int Tout, unsigned flags, hipStream_t st);
 
 // fused stem
 size_t stem_prep_bytes(int Cin, int C, int K, int S, unsigned flags);

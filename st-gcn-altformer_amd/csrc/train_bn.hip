@@ -44,15 +44,19 @@ __global__ __launch_bounds__(256) void bn_batch_stats_kernel(const float *__rest
 __global__ void bn_train_finalize_kernel(const double *__restrict__ sums, double count, const float *__restrict__ weight,
                                          const float *__restrict__ bias, float *__restrict__ running_mean,
                                          float *__restrict__ running_var, float momentum, float eps,
-                                         float *__restrict__ scale, float *__restrict__ shift, int C) {
+                                         float *__restrict__ scale, float *__restrict__ shift, int C,
+                                         float *__restrict__ save_mean, float *__restrict__ save_invstd) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const double mean = sums[c] / count;
     double var = sums[C + c] / count - mean * mean;
     if (var < 0.0) var = 0.0;
-    const float s = weight[c] / sqrtf((float)var + eps);
+    const float inv = 1.f / sqrtf((float)var + eps);
+    const float s = weight[c] * inv;
     scale[c] = s;
     shift[c] = bias[c] - (float)mean * s;
+    if (save_mean) save_mean[c] = (float)mean;       // what the backward needs (torch's save_mean / save_invstd)
+    if (save_invstd) save_invstd[c] = inv;
     const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
@@ -71,7 +75,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
     }
 }
 
+// scale/shift of y = z*scale + shift from the saved batch statistics (backward: the ReLU mask needs the forward's y)
+__global__ void bn_scale_shift_kernel(const float *__restrict__ weight, const float *__restrict__ bias,
+                                      const float *__restrict__ mean, const float *__restrict__ invstd,
+                                      float *__restrict__ scale, float *__restrict__ shift, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float s = weight[c] * invstd[c];
+    scale[c] = s;
+    shift[c] = bias[c] - mean[c] * s;
+}
+
 }  // namespace
+
+int launch_bn_scale_shift(const float *weight, const float *bias, const float *mean, const float *invstd, float *scale,
+                          float *shift, int C, hipStream_t st) {
+    hipLaunchKernelGGL(bn_scale_shift_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, weight, bias, mean, invstd, scale,
+                       shift, C);
+    STGCN_LAUNCH_CHECK("bn_scale_shift_kernel");
+    return STGCN_OK;
+}
 
 int launch_bn_batch_stats(const float *z, double *sums, int N, int C, size_t plane, hipStream_t st) {
     STGCN_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
@@ -86,9 +109,9 @@ int launch_bn_batch_stats(const float *z, double *sums, int N, int C, size_t pla
 
 int launch_bn_train_finalize(const double *sums, double count, const float *weight, const float *bias,
                              float *running_mean, float *running_var, float momentum, float eps, float *scale,
-                             float *shift, int C, hipStream_t st) {
+                             float *shift, int C, hipStream_t st, float *save_mean, float *save_invstd) {
     hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, count, weight, bias,
-                       running_mean, running_var, momentum, eps, scale, shift, C);
+                       running_mean, running_var, momentum, eps, scale, shift, C, save_mean, save_invstd);
     STGCN_LAUNCH_CHECK("bn_train_finalize_kernel");
     return STGCN_OK;
 }

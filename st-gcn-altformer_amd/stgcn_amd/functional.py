@@ -247,8 +247,10 @@ def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_
     return y, P
 
 
-def tcn_forward_train(x, W, conv_bias, bn, stride=1, math=MATH_F32, momentum=0.1, eps=BN_EPS):
-    """Training-mode forward of Unit2D(dim=2, dropout=0): raw conv -> batch statistics -> normalise -> ReLU."""
+def tcn_forward_train(x, W, conv_bias, bn, stride=1, math=MATH_F32, momentum=0.1, eps=BN_EPS, save=False):
+    """Training-mode forward of Unit2D(dim=2, dropout=0): raw conv -> batch statistics -> normalise -> ReLU.
+
+    ``save=True`` also returns what the backward needs: (y, z = conv_t(x)+b, batch mean, batch invstd)."""
     dev = x.device
     N, Cin, T, V = x.shape
     Cout, _, K = W.shape
@@ -259,12 +261,40 @@ def tcn_forward_train(x, W, conv_bias, bn, stride=1, math=MATH_F32, momentum=0.1
     nbytes = _capi.lib().stgcn_tcn_train_ws_bytes(N, Cin, Cout, T, V, K, stride, fl)
     ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
     y = torch.empty(N, Cout, Tout, V, device=dev, dtype=torch.float32)
+    z = torch.empty_like(y) if save else None
+    mean = torch.empty(Cout, device=dev, dtype=torch.float32) if save else None
+    invstd = torch.empty(Cout, device=dev, dtype=torch.float32) if save else None
     with torch.cuda.device(dev):
         _capi.call("stgcn_tcn_forward_train", _dev_ptr(x, "x", dev), _dev_ptr(W, "W", dev),
                    _dev_ptr(conv_bias, "conv_bias", dev), *[_dev_ptr(t, "bn", dev) for t in bn], c_float(momentum),
-                   c_float(eps), c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), _dev_ptr(y, "y"), c_int(N), c_int(Cin),
-                   c_int(Cout), c_int(T), c_int(V), c_int(K), c_int(stride), c_uint(fl), _stream(dev))
-    return y
+                   c_float(eps), c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), _dev_ptr(y, "y"),
+                   _dev_ptr(z, "save_z"), _dev_ptr(mean, "save_mean"), _dev_ptr(invstd, "save_invstd"), c_int(N),
+                   c_int(Cin), c_int(Cout), c_int(T), c_int(V), c_int(K), c_int(stride), c_uint(fl), _stream(dev))
+    return (y, z, mean, invstd) if save else y
+
+
+def tcn_backward_train(x, W, z, bn_weight, bn_bias, mean, invstd, dy, stride=1, math=MATH_F32, need_dx=True,
+                       has_bias=True):
+    """Backward of the training-mode Unit2D forward: returns (dx | None, dW (Cout,Cin,K), dbias | None, dgamma, dbeta)."""
+    dev = x.device
+    N, Cin, T, V = x.shape
+    Cout, _, K = W.shape
+    fl = _flags(math, False)
+    nbytes = _capi.lib().stgcn_tcn_backward_ws_bytes(N, Cin, Cout, T, V, K, stride, fl)
+    ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
+    dx = torch.empty_like(x) if need_dx else None
+    dW = torch.empty_like(W)
+    dbias = torch.empty(Cout, device=dev, dtype=torch.float32) if has_bias else None
+    dgamma = torch.empty(Cout, device=dev, dtype=torch.float32)
+    dbeta = torch.empty(Cout, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_tcn_backward_train", _dev_ptr(x, "x", dev), _dev_ptr(W, "W", dev), _dev_ptr(z, "z", dev),
+                   _dev_ptr(bn_weight, "bn_weight", dev), _dev_ptr(bn_bias, "bn_bias", dev), _dev_ptr(mean, "mean", dev),
+                   _dev_ptr(invstd, "invstd", dev), _dev_ptr(dy, "dy", dev), _dev_ptr(dx, "dx"), _dev_ptr(dW, "dW"),
+                   _dev_ptr(dbias, "dbias"), _dev_ptr(dgamma, "dgamma"), _dev_ptr(dbeta, "dbeta"),
+                   c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), c_int(N), c_int(Cin), c_int(Cout), c_int(T), c_int(V),
+                   c_int(K), c_int(stride), c_uint(fl), _stream(dev))
+    return dx, dW, dbias, dgamma, dbeta
 
 
 class KernelTimer:

@@ -41,8 +41,12 @@ def _versions(mod: nn.Module):
     return tuple(t._version for t in list(mod.parameters()) + list(mod.buffers()))
 
 
-def _check_input(mod: nn.Module, x: torch.Tensor):
-    if mod.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mod.parameters())):
+def _wants_grad(mod: nn.Module, x: torch.Tensor) -> bool:
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mod.parameters()))
+
+
+def _check_input(mod: nn.Module, x: torch.Tensor, backward_ok: bool = False):
+    if not backward_ok and mod.training and _wants_grad(mod, x):
         raise NotImplementedError(
             f"{type(mod).__name__}: the HIP path implements the forward only (eval, and training-mode forward with "
             "batch-statistics BatchNorm under torch.no_grad()); autograd/backward is not implemented "
@@ -58,6 +62,32 @@ def _check_input(mod: nn.Module, x: torch.Tensor):
 
 
 # ----------------------------------------------------------------------------------------
+class _Unit2DTrainFn(torch.autograd.Function):
+    """relu(BatchNorm_batch(conv_t(x) + b)) with the HIP forward and backward (model/net.py:47-57 in .train())."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn_weight, bn_bias, running_mean, running_var, stride, mode, momentum, eps):
+        Cout, Cin, K = weight.shape[0], weight.shape[1], weight.shape[2]
+        W = weight.detach().reshape(Cout, Cin, K).contiguous()
+        bnw = bn_weight.detach() if bn_weight is not None else None
+        if bn_weight is None or bn_bias is None:
+            raise NotImplementedError("Unit2D: the HIP training path needs an affine BatchNorm")
+        y, z, mean, invstd = F.tcn_forward_train(x.detach(), W, None if bias is None else bias.detach(),
+                                                 (bnw, bn_bias.detach(), running_mean, running_var), stride, mode,
+                                                 momentum, eps, save=True)
+        ctx.save_for_backward(x.detach(), W, z, bnw, bn_bias.detach(), mean, invstd)
+        ctx.meta = (stride, mode, bias is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, z, bnw, bnb, mean, invstd = ctx.saved_tensors
+        stride, mode, has_bias, wshape = ctx.meta
+        dx, dW, db, dgamma, dbeta = F.tcn_backward_train(x, W, z, bnw, bnb, mean, invstd, dy.contiguous(), stride, mode,
+                                                         need_dx=ctx.needs_input_grad[0], has_bias=has_bias)
+        return (dx, dW.view(wshape), db if has_bias else None, dgamma, dbeta, None, None, None, None, None, None)
+
+
 def conv_init(module):
     """He-normal on the weight only (model/net.py:60-65)."""
     n = module.out_channels
@@ -303,7 +333,7 @@ class Unit2D(nn.Module):
     def forward(self, x):
         if getattr(x, "_stgcn_fused_for", None) is self:
             return x                      # produced by the fused stem kernel in unit_agcn.forward
-        _check_input(self, x)
+        _check_input(self, x, backward_ok=self.dim == 2)
         if x.shape[1] != self.conv.in_channels:
             raise RuntimeError(f"Unit2D: expected {self.conv.in_channels} input channels, got {x.shape[1]}")
         if self.dim == 3:
@@ -321,9 +351,13 @@ class Unit2D(nn.Module):
             if bn.momentum is None or not bn.track_running_stats:
                 raise NotImplementedError("Unit2D: training-mode BatchNorm needs momentum and running statistics")
             c = self.conv
-            W = c.weight.detach().reshape(c.out_channels, c.in_channels, self.kernel_size).contiguous()
-            y = F.tcn_forward_train(x, W, c.bias, (bn.weight, bn.bias, bn.running_mean, bn.running_var), self.stride,
-                                    mode, bn.momentum, bn.eps)
+            if _wants_grad(self, x):         # autograd: HIP forward + HIP backward (tcn_backward.hip)
+                y = _Unit2DTrainFn.apply(x, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                         self.stride, mode, bn.momentum, bn.eps)
+            else:
+                W = c.weight.detach().reshape(c.out_channels, c.in_channels, self.kernel_size).contiguous()
+                y = F.tcn_forward_train(x, W, c.bias, (bn.weight, bn.bias, bn.running_mean, bn.running_var), self.stride,
+                                        mode, bn.momentum, bn.eps)
             with torch.no_grad():
                 bn.num_batches_tracked += 1
         else:

@@ -375,11 +375,11 @@ def test_stem_train_forward_vs_golden(dev):
     parity_gate(tcn.bn.running_var, g["after_train.tcn.bn.running_var"], 1e-4, "tcn running_var after one step")
 
 
-def test_backward_is_refused_loudly(dev):
+def test_unsupported_backward_is_refused_loudly(dev):
     from stgcn_amd import Unit2D
-    m = Unit2D(16, 128, kernel_size=9).to(dev).train()
+    m = Unit2D(16, 128, kernel_size=9, dim=3).to(dev).train()   # dim=3 (transposed) has no HIP backward
     with pytest.raises(NotImplementedError, match="backward"):
-        m(torch.zeros(1, 16, 8, 22, device=dev))          # grad enabled + trainable parameters
+        m(torch.zeros(1, 16, 22, 8, device=dev))          # grad enabled + trainable parameters
 
 
 @pytest.mark.parametrize("N", [17, 33])
@@ -474,3 +474,68 @@ def test_two_stage_path_accepts_channels_last_input(dev):
         a = tcn(gcn(batch.permute(0, 3, 1, 2)))
         b = tcn(gcn(batch.permute(0, 3, 1, 2).contiguous()))
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------
+# SURVEY §8(f) rank 2 — backward of the training-mode blocks, against autograd through the fp64 oracle
+# ---------------------------------------------------------------------------------------
+def _grad_gate(got, ref, rel, what):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite gradient"
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert err <= rel * max(scale, 1e-30), f"{what}: max abs err {err:.3e} > {rel:g} * max|ref| ({scale:.3e})"
+
+
+def _kink_free_cotangent(y_ref, gen):
+    """Random dL/dy that is zero where the reference output sits within 1e-4*max of the ReLU kink.  The gradient is
+    discontinuous there: an output of 1e-6 that the fp32 path rounds to 0 flips one mask bit and moves dbeta of its
+    channel by a whole |dL/dy| — a property of ReLU, not an arithmetic error — so those outputs carry no cotangent."""
+    G = torch.randn(y_ref.shape, generator=gen)
+    return G * (y_ref.detach() > 1e-4 * y_ref.detach().abs().max()).float()
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "f32", "f32_valu"])
+@pytest.mark.parametrize("cin,cout,K,stride,N,T,V,bias", [
+    (128, 128, 9, 1, 3, 21, 22, True),     # the stem's block: matrix-core wgrad + forward kernel as dgrad
+    (128, 128, 9, 1, 2, 10, 46, True),     # 46 joints: other frame padding / frames per unit in the wgrad
+    (64, 128, 9, 2, 2, 21, 22, True),      # strided: plain fp32 kernels
+    (32, 64, 5, 1, 2, 9, 22, False),       # no conv bias, K = 5, 64 output channels
+    (64, 128, 1, 1, 2, 12, 25, True)])     # 1x1 (the residual "down" convs of the deeper layers)
+def test_unit2d_backward_vs_oracle(cin, cout, K, stride, N, T, V, bias, math, dev):
+    from stgcn_amd import Unit2D, set_math_mode
+    from oracle import stgcn_oracle as so
+    torch.manual_seed(900 + cin + K + V)
+    gen = torch.Generator().manual_seed(901 + cin + K + V)
+    m = Unit2D(cin, cout, kernel_size=K, stride=stride, bias=bias)
+    with torch.no_grad():
+        m.bn.weight.copy_(torch.rand(cout, generator=gen) + 0.5)
+        m.bn.bias.copy_(torch.randn(cout, generator=gen) * 0.2)
+        if bias:
+            m.conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
+    set_math_mode(m, math)
+    tp = so.tcn_params_from_state(m.state_dict(), stride=stride).to(torch.float64)
+    x = torch.randn(N, cin, T, V, generator=gen)
+    # oracle: autograd through the fp64 restatement
+    leaves = [tp.conv_w, tp.bn.weight, tp.bn.bias] + ([tp.conv_b] if bias else [])
+    for t in leaves:
+        t.requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    yr = so.tcn_forward(xr, tp, training=True)
+    G = _kink_free_cotangent(yr, gen)
+    grads = torch.autograd.grad((yr * G.double()).sum(), leaves + [xr])
+    # HIP path
+    m = m.to(dev).train()
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    parity_gate(y.detach(), yr.detach(), 1e-4, "training-mode forward")
+    (y * G.to(dev)).sum().backward()
+    gate = 1e-4
+    _grad_gate(m.conv.weight.grad.reshape(cout, cin, K), grads[0], gate, "dW")
+    _grad_gate(m.bn.weight.grad, grads[1], gate, "dgamma")
+    _grad_gate(m.bn.bias.grad, grads[2], gate, "dbeta")
+    _grad_gate(xd.grad, grads[-1], gate, "dx")
+    if bias:   # analytically zero behind a batch-statistics BatchNorm: both sides are rounding noise
+        assert m.conv.bias.grad.abs().max().item() <= 1e-3 * grads[2].abs().max().item()
+        assert grads[3].abs().max().item() <= 1e-6 * grads[2].abs().max().item()

@@ -171,8 +171,26 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
                              const float *bn_bias, float *bn_running_mean, float *bn_running_var,
                              const float *dbn_weight, const float *dbn_bias, float *dbn_running_mean,
                              float *dbn_running_var, float momentum, float eps, float *P_ws, void *ws,
-                             size_t ws_bytes, float *y, int N, int Cin, int Cout, int T, int V,
-                             int inter_c, int subsets, void *stream);
+                             size_t ws_bytes, float *y, float *save_zm, float *save_zd, float *save_stats,
+                             int N, int Cin, int Cout, int T, int V, int inter_c, int subsets,
+                             void *stream);
+/* save_zm / save_zd (N,Cout,T,V): the two pre-BatchNorm branches (sum_s conv_d_s(x P_s), conv_down(x));
+ * save_stats (4*Cout): batch mean, invstd of `bn`, then of the down BatchNorm.  Optional (NULL), for the
+ * backward: */
+size_t stgcn_agcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets); /* 0: shape not covered */
+/* Gradients of every parameter of unit_agcn (model/unit_agcn.py:35-62) from dy (N,Cout,T,V) in training mode:
+ * dWa/dWb (S,inter_c,Cin), dba/dbb (S,inter_c), dWd (S,Cout,Cin), dbd (S,Cout), dWdown (Cout,Cin), dbdown, the
+ * two BatchNorms' dgamma/dbeta (main, then "dd" = down), dPA (S,V,V).  x is data: no dx.  Covers the stem's
+ * shape class (Cin = 3, 3 subsets, Cout in {64,128,256}, down branch present); else STGCN_ERR_UNSUPPORTED. */
+int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *Wa, const float *ba,
+                              const float *Wb, const float *bb, const float *Wd, const float *P,
+                              const float *zm, const float *zd, const float *bn_weight,
+                              const float *bn_bias, const float *dbn_weight, const float *dbn_bias,
+                              const float *save_stats, const float *dy, float *dWa, float *dba, float *dWb,
+                              float *dbb, float *dWd, float *dbd, float *dWdown, float *dbdown,
+                              float *dgamma, float *dbeta, float *ddgamma, float *ddbeta, float *dPA,
+                              void *ws, size_t ws_bytes, int N, int Cin, int Cout, int T, int V,
+                              int inter_c, int subsets, void *stream);
 size_t stgcn_tcn_train_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
 /* save_z (N,Cout,T_out,V), save_mean, save_invstd (Cout): optional outputs for the backward — the raw
  * convolution conv_t(x)+b and the batch statistics, torch's save_mean / save_invstd.  NULL: not kept. */

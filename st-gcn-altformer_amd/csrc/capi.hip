@@ -264,8 +264,8 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
                              const float *bdown, const float *bn_weight, const float *bn_bias, float *bn_running_mean,
                              float *bn_running_var, const float *dbn_weight, const float *dbn_bias,
                              float *dbn_running_mean, float *dbn_running_var, float momentum, float eps, float *P_ws,
-                             void *ws, size_t ws_bytes, float *y, int N, int Cin, int Cout, int T, int V, int inter_c,
-                             int subsets, void *stream) {
+                             void *ws, size_t ws_bytes, float *y, float *save_zm, float *save_zd, float *save_stats,
+                             int N, int Cin, int Cout, int T, int V, int inter_c, int subsets, void *stream) {
     REQUIRE_PTR(Wd); REQUIRE_PTR(bd); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias); REQUIRE_PTR(bn_running_mean);
     REQUIRE_PTR(bn_running_var); REQUIRE_PTR(ws); REQUIRE_PTR(y); REQUIRE_POS(Cout);
     const bool has_down = Wdown != nullptr;
@@ -280,8 +280,11 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
     hipStream_t st = (hipStream_t)stream;
     float *ones = (float *)ws, *zeros = ones + Cout, *s1 = zeros + Cout, *t1 = s1 + Cout, *s2 = t1 + Cout, *t2 = s2 + Cout;
     double *sums1 = (double *)(t2 + Cout), *sums2 = sums1 + 2 * Cout;
-    float *zm = (float *)((char *)ws + train_small_bytes(Cout));
-    float *zd = zm + (size_t)N * Cout * T * V;
+    float *zm = save_zm ? save_zm : (float *)((char *)ws + train_small_bytes(Cout));
+    float *zd = save_zd ? save_zd : (float *)((char *)ws + train_small_bytes(Cout)) + (size_t)N * Cout * T * V;
+    // save_stats (4*Cout): batch mean, invstd of the main BatchNorm, then of the down BatchNorm
+    float *sv_mm = save_stats, *sv_im = save_stats ? save_stats + Cout : nullptr;
+    float *sv_md = save_stats ? save_stats + 2 * Cout : nullptr, *sv_id = save_stats ? save_stats + 3 * Cout : nullptr;
     const size_t plane = (size_t)T * V, total = (size_t)N * Cout * plane;
     hipLaunchKernelGGL(fill_ones_zeros_kernel, dim3(ceil_div(Cout, 256)), dim3(256), 0, st, ones, zeros, Cout);
     STGCN_LAUNCH_CHECK("fill_ones_zeros_kernel");
@@ -292,7 +295,7 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
     rc = launch_bn_batch_stats(zm, sums1, N, Cout, plane, st);
     if (rc != STGCN_OK) return rc;
     rc = launch_bn_train_finalize(sums1, (double)N * plane, bn_weight, bn_bias, bn_running_mean, bn_running_var, momentum,
-                                  eps, s1, t1, Cout, st);
+                                  eps, s1, t1, Cout, st, sv_mm, sv_im);
     if (rc != STGCN_OK) return rc;
     if (has_down) {  // residual branch, pre-BN: conv_down(x)
         rc = launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, zeros, zeros, ones, zeros, zd, N, Cin, Cout, T, V, subsets,
@@ -301,11 +304,65 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
         rc = launch_bn_batch_stats(zd, sums2, N, Cout, plane, st);
         if (rc != STGCN_OK) return rc;
         rc = launch_bn_train_finalize(sums2, (double)N * plane, dbn_weight, dbn_bias, dbn_running_mean, dbn_running_var,
-                                      momentum, eps, s2, t2, Cout, st);
+                                      momentum, eps, s2, t2, Cout, st, sv_md, sv_id);
         if (rc != STGCN_OK) return rc;
         return launch_bn_apply(zm, s1, t1, zd, s2, t2, y, total, Cout, plane, st);
     }
     return launch_bn_apply(zm, s1, t1, x, nullptr, nullptr, y, total, Cout, plane, st);  // identity residual: + x
+}
+
+// ---- backward of the training-mode graph conv (stem shape class) --------------------------------------------------
+// workspace: [sums 3C dbl][coef_m 3C][coef_d 3C][scale_m, shift_m, scale_d, shift_d] | per-workgroup partials
+static size_t agcn_bwd_small_bytes(int Cout) {
+    return align_up((size_t)Cout * 3 * sizeof(double) + (size_t)Cout * 10 * sizeof(float), 256);
+}
+
+size_t stgcn_agcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || subsets <= 0) return 0;
+    const size_t part = agcn_bwd_part_bytes(N, Cin, Cout, T, V, subsets);
+    return part ? agcn_bwd_small_bytes(Cout) + part : 0;   // 0: shape not covered
+}
+
+int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *Wa, const float *ba, const float *Wb,
+                              const float *bb, const float *Wd, const float *P, const float *zm, const float *zd,
+                              const float *bn_weight, const float *bn_bias, const float *dbn_weight,
+                              const float *dbn_bias, const float *save_stats, const float *dy, float *dWa, float *dba,
+                              float *dWb, float *dbb, float *dWd, float *dbd, float *dWdown, float *dbdown, float *dgamma,
+                              float *dbeta, float *ddgamma, float *ddbeta, float *dPA, void *ws, size_t ws_bytes, int N,
+                              int Cin, int Cout, int T, int V, int inter_c, int subsets, void *stream) {
+    REQUIRE_PTR(x); REQUIRE_PTR(A_eff); REQUIRE_PTR(Wa); REQUIRE_PTR(ba); REQUIRE_PTR(Wb); REQUIRE_PTR(bb); REQUIRE_PTR(Wd);
+    REQUIRE_PTR(P); REQUIRE_PTR(zm); REQUIRE_PTR(zd); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias); REQUIRE_PTR(dbn_weight);
+    REQUIRE_PTR(dbn_bias); REQUIRE_PTR(save_stats); REQUIRE_PTR(dy); REQUIRE_PTR(dWa); REQUIRE_PTR(dba); REQUIRE_PTR(dWb);
+    REQUIRE_PTR(dbb); REQUIRE_PTR(dWd); REQUIRE_PTR(dbd); REQUIRE_PTR(dWdown); REQUIRE_PTR(dbdown); REQUIRE_PTR(dgamma);
+    REQUIRE_PTR(dbeta); REQUIRE_PTR(ddgamma); REQUIRE_PTR(ddbeta); REQUIRE_PTR(dPA); REQUIRE_PTR(ws);
+    REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(Cout); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(inter_c); REQUIRE_POS(subsets);
+    if (!agcn_bwd_supported(N, Cin, Cout, T, V, subsets))
+        return fail(STGCN_ERR_UNSUPPORTED,
+                    "agcn_backward: covers Cin=3, 3 subsets, Cout in {64,128,256}, a down branch (got Cin=%d S=%d Cout=%d V=%d)",
+                    Cin, subsets, Cout, V);
+    const size_t need = stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, subsets);
+    if (ws_bytes < need) return fail(STGCN_ERR_WORKSPACE, "agcn_backward: workspace %zu B < %zu B", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t plane = (size_t)T * V;
+    double *sums = (double *)ws;
+    float *coefm = (float *)(sums + 3 * Cout), *coefd = coefm + 3 * Cout, *sm_ = coefd + 3 * Cout, *tm_ = sm_ + Cout,
+          *sd_ = tm_ + Cout, *td_ = sd_ + Cout;
+    float *part = (float *)((char *)ws + agcn_bwd_small_bytes(Cout));
+    const float *mean_m = save_stats, *inv_m = save_stats + Cout, *mean_d = save_stats + 2 * Cout, *inv_d = save_stats + 3 * Cout;
+    int rc = launch_bn_scale_shift(bn_weight, bn_bias, mean_m, inv_m, sm_, tm_, Cout, st);
+    if (rc != STGCN_OK) return rc;
+    rc = launch_bn_scale_shift(dbn_weight, dbn_bias, mean_d, inv_d, sd_, td_, Cout, st);
+    if (rc != STGCN_OK) return rc;
+    rc = launch_bn_relu_bwd_stats(zm, sm_, tm_, mean_m, inv_m, zd, sd_, td_, mean_d, inv_d, dy, sums, N, Cout, plane, st);
+    if (rc != STGCN_OK) return rc;
+    rc = launch_bn_bwd_finalize(sums, 1, (double)N * plane, bn_weight, inv_m, dgamma, dbeta, coefm, Cout, st);
+    if (rc != STGCN_OK) return rc;
+    rc = launch_bn_bwd_finalize(sums, 2, (double)N * plane, dbn_weight, inv_d, ddgamma, ddbeta, coefd, Cout, st);
+    if (rc != STGCN_OK) return rc;
+    const float *const m_[6] = {zm, sm_, tm_, mean_m, inv_m, coefm};
+    const float *const d_[6] = {zd, sd_, td_, mean_d, inv_d, coefd};
+    return launch_agcn_bwd(x, P, A_eff, m_, d_, dy, Wa, ba, Wb, bb, Wd, part, dWa, dba, dWb, dbb, dWd, dbd, dWdown, dbdown,
+                           dPA, N, Cin, Cout, T, V, inter_c, subsets, st);
 }
 
 // workspace layout (tcn): [ones C][zeros C][scale, shift][sums 2C doubles][packed weights][z N*Cout*Tout*V]

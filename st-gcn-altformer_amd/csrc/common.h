@@ -134,6 +134,14 @@ size_t tcn_wgrad_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int str
 int launch_tcn_wgrad(const float *dz, const float *x, float *dW, float *part, int N, int Cin, int Cout, int T, int V, int K,
                      int stride, int Tout, unsigned flags, hipStream_t st);
 
+// backward of the training-mode graph conv (agcn_backward.hip)
+bool agcn_bwd_supported(int N, int Cin, int Cout, int T, int V, int S);
+size_t agcn_bwd_part_bytes(int N, int Cin, int Cout, int T, int V, int S);
+int launch_agcn_bwd(const float *x, const float *P, const float *A_eff, const float *const m_[6], const float *const d_[6],
+                    const float *dy, const float *Wa, const float *ba, const float *Wb, const float *bb, const float *Wd,
+                    float *part, float *dWa, float *dba, float *dWb, float *dbb, float *dWd, float *dbd, float *dWdown,
+                    float *dbdown, float *dPA, int N, int Cin, int Cout, int T, int V, int inter_c, int S, hipStream_t st);
+
 // fused stem
 size_t stem_prep_bytes(int Cin, int C, int K, int S, unsigned flags);
 int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, const float *bdown,

@@ -223,10 +223,12 @@ def stem_forward(x, A_eff, Wa, ba, Wb, bb, prep, t_shift, C, K, math=MATH_F32, o
     return out, ws[:N * S * V * V].view(N, S, V, V)
 
 
-def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_bn, momentum=0.1, eps=BN_EPS):
+def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_bn, momentum=0.1, eps=BN_EPS,
+                       save=False):
     """Training-mode forward of unit_agcn (batch-statistics BatchNorm; running buffers of `bn` / `down_bn` are
     updated in place like torch does).  bn / down_bn: (weight, bias, running_mean, running_var) tensors.
-    Returns (y, P).  Forward only."""
+    Returns (y, P); with ``save=True`` (y, P, zm, zd, stats) — the pre-BatchNorm branches and the batch
+    mean / invstd of both BatchNorms (4*Cout), which the backward reads."""
     dev = x.device
     N, Cin, T, V = x.shape
     S, inter_c, _ = Wa.shape
@@ -236,15 +238,52 @@ def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_
     nbytes = _capi.lib().stgcn_agcn_train_ws_bytes(N, Cout, T, V)
     ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
     d = down_bn if down_bn is not None else (None, None, None, None)
+    zm = torch.empty_like(y) if save else None
+    zd = torch.empty_like(y) if save else None
+    stats = torch.empty(4 * Cout, device=dev, dtype=torch.float32) if save else None
     with torch.cuda.device(dev):
         _capi.call("stgcn_agcn_forward_train", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev),
                    _dev_ptr(Wa, "Wa", dev), _dev_ptr(ba, "ba", dev), _dev_ptr(Wb, "Wb", dev), _dev_ptr(bb, "bb", dev),
                    _dev_ptr(Wd, "Wd", dev), _dev_ptr(bd, "bd", dev), _dev_ptr(Wdown, "Wdown", dev),
                    _dev_ptr(bdown, "bdown", dev), *[_dev_ptr(t, "bn", dev) for t in bn],
                    *[_dev_ptr(t, "down_bn", dev) for t in d], c_float(momentum), c_float(eps), _dev_ptr(P, "P"),
-                   c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), _dev_ptr(y, "y"), c_int(N), c_int(Cin), c_int(Cout),
+                   c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), _dev_ptr(y, "y"), _dev_ptr(zm, "save_zm"),
+                   _dev_ptr(zd, "save_zd"), _dev_ptr(stats, "save_stats"), c_int(N), c_int(Cin), c_int(Cout),
                    c_int(T), c_int(V), c_int(inter_c), c_int(S), _stream(dev))
-    return y, P
+    return (y, P, zm, zd, stats) if save else (y, P)
+
+
+def agcn_backward_supported(N, Cin, Cout, T, V, S) -> bool:
+    return _capi.lib().stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, S) > 0
+
+
+def agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, P, zm, zd, bn_weight, bn_bias, dbn_weight, dbn_bias, stats, dy):
+    """Parameter gradients of the training-mode unit_agcn forward (x is data: no dx).  Returns a dict keyed
+    dWa, dba, dWb, dbb, dWd, dbd, dWdown, dbdown, dgamma, dbeta, ddgamma, ddbeta, dPA."""
+    dev = x.device
+    N, Cin, T, V = x.shape
+    S, inter_c, _ = Wa.shape
+    Cout = Wd.shape[1]
+    nbytes = _capi.lib().stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, S)
+    if nbytes == 0:
+        raise NotImplementedError(f"unit_agcn backward: shape Cin={Cin} S={S} Cout={Cout} V={V} is not covered by the HIP path")
+    ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
+    f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    g = dict(dWa=f(S, inter_c, Cin), dba=f(S, inter_c), dWb=f(S, inter_c, Cin), dbb=f(S, inter_c), dWd=f(S, Cout, Cin),
+             dbd=f(S, Cout), dWdown=f(Cout, Cin), dbdown=f(Cout), dgamma=f(Cout), dbeta=f(Cout), ddgamma=f(Cout),
+             ddbeta=f(Cout), dPA=f(S, V, V))
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_agcn_backward_train", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev), _dev_ptr(Wa, "Wa", dev),
+                   _dev_ptr(ba, "ba", dev), _dev_ptr(Wb, "Wb", dev), _dev_ptr(bb, "bb", dev), _dev_ptr(Wd, "Wd", dev),
+                   _dev_ptr(P, "P", dev), _dev_ptr(zm, "zm", dev), _dev_ptr(zd, "zd", dev),
+                   _dev_ptr(bn_weight, "bn_weight", dev), _dev_ptr(bn_bias, "bn_bias", dev),
+                   _dev_ptr(dbn_weight, "dbn_weight", dev), _dev_ptr(dbn_bias, "dbn_bias", dev),
+                   _dev_ptr(stats, "stats", dev), _dev_ptr(dy, "dy", dev),
+                   *[_dev_ptr(g[k], k) for k in ("dWa", "dba", "dWb", "dbb", "dWd", "dbd", "dWdown", "dbdown", "dgamma",
+                                                 "dbeta", "ddgamma", "ddbeta", "dPA")],
+                   c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), c_int(N), c_int(Cin), c_int(Cout), c_int(T),
+                   c_int(V), c_int(inter_c), c_int(S), _stream(dev))
+    return g
 
 
 def tcn_forward_train(x, W, conv_bias, bn, stride=1, math=MATH_F32, momentum=0.1, eps=BN_EPS, save=False):

@@ -88,6 +88,35 @@ class _Unit2DTrainFn(torch.autograd.Function):
         return (dx, dW.view(wshape), db if has_bias else None, dgamma, dbeta, None, None, None, None, None, None)
 
 
+class _AgcnTrainFn(torch.autograd.Function):
+    """unit_agcn.forward in .train() with the HIP forward and backward (parameter gradients; x is data)."""
+
+    @staticmethod
+    def forward(ctx, mod, x, *params):               # `params` = mod._train_params(): graph edges only, values via _staged
+        st = mod._staged(x.device)
+        bn, d = mod.bn, mod.down[1]
+        y, P, zm, zd, stats = F.agcn_forward_train(
+            x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"], st["bdown"],
+            (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var),
+            (d.weight.detach(), d.bias.detach(), d.running_mean, d.running_var), bn.momentum, bn.eps, save=True)
+        ctx.save_for_backward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], P, zm, zd,
+                              bn.weight.detach(), bn.bias.detach(), d.weight.detach(), d.bias.detach(), stats)
+        ctx.S = mod.num_subset
+        mod.last_attention = P
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = F.agcn_backward_train(*ctx.saved_tensors, dy.contiguous())
+        S = ctx.S
+        out = [g["dPA"]]
+        for w, b in (("dWa", "dba"), ("dWb", "dbb"), ("dWd", "dbd")):
+            for i in range(S):
+                out += [g[w][i].unsqueeze(-1).unsqueeze(-1), g[b][i]]
+        out += [g["dWdown"].unsqueeze(-1).unsqueeze(-1), g["dbdown"], g["ddgamma"], g["ddbeta"], g["dgamma"], g["dbeta"]]
+        return (None, None, *out)
+
+
 def conv_init(module):
     """He-normal on the weight only (model/net.py:60-65)."""
     n = module.out_channels
@@ -225,7 +254,7 @@ class unit_agcn(nn.Module):
         return F.stem_supported(C, self.out_channels, T, V, t.kernel_size, self.num_subset, t.math_mode)
 
     def forward(self, x):
-        _check_input(self, x)
+        _check_input(self, x, backward_ok=True)      # (_forward_train refuses the shapes without a HIP backward)
         if x.shape[1] != self.in_channels:
             raise RuntimeError(f"unit_agcn: expected {self.in_channels} input channels, got {x.shape[1]}")
         if x.shape[3] != self.PA.shape[-1]:
@@ -258,11 +287,32 @@ class unit_agcn(nn.Module):
         return y
 
 
+    def _train_params(self):
+        """Parameters in the order _AgcnTrainFn.backward returns their gradients."""
+        ps = [self.PA]
+        for convs in (self.conv_a, self.conv_b, self.conv_d):
+            for c in convs:
+                ps += [c.weight, c.bias]
+        return ps + [self.down[0].weight, self.down[0].bias, self.down[1].weight, self.down[1].bias, self.bn.weight,
+                     self.bn.bias]
+
     def _forward_train(self, x, st):
         """Batch-statistics BatchNorm forward (model/unit_agcn.py:91-92 with self.training); updates running buffers."""
         bn = self.bn
         if bn.momentum is None or not bn.track_running_stats:
             raise NotImplementedError("unit_agcn: training-mode BatchNorm needs momentum and running statistics")
+        if _wants_grad(self, x):                   # autograd: HIP forward + HIP backward (agcn_backward.hip)
+            N, C, T, V = x.shape
+            if x.requires_grad or not self._has_down() or not F.agcn_backward_supported(N, C, self.out_channels, T, V,
+                                                                                        self.num_subset):
+                raise NotImplementedError(
+                    "unit_agcn: the HIP backward covers the stem's shape class (C_in = 3, 3 subsets, C_out in "
+                    "{64,128,256}, input without gradient); this call is outside it (SURVEY.md §8f rank 3)")
+            y = _AgcnTrainFn.apply(self, x, *self._train_params())
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                self.down[1].num_batches_tracked += 1
+            return y
         down_bn = None
         if self._has_down():
             d = self.down[1]

@@ -259,9 +259,11 @@ def test_full_size_properties(math, dev):
 
 def test_errors_are_loud(dev):
     from stgcn_amd import Unit2D, functional as F, StgcnError
+    from stgcn_amd import unit_agcn
     m = Unit2D(8, 8, kernel_size=3).to(dev)
+    g = unit_agcn(8, 8, torch.rand(3, 4, 4)).to(dev)
     with pytest.raises(NotImplementedError):
-        m.train()(torch.zeros(1, 8, 4, 4, device=dev))   # autograd would be needed: refused
+        g.train()(torch.zeros(1, 8, 4, 4, device=dev))   # autograd outside the shapes the HIP backward covers: refused
     with pytest.raises(RuntimeError):
         m.eval()(torch.zeros(1, 8, 4, 4))            # CPU tensor: no fallback
     with pytest.raises(ValueError):
@@ -539,3 +541,103 @@ def test_unit2d_backward_vs_oracle(cin, cout, K, stride, N, T, V, bias, math, de
     if bias:   # analytically zero behind a batch-statistics BatchNorm: both sides are rounding noise
         assert m.conv.bias.grad.abs().max().item() <= 1e-3 * grads[2].abs().max().item()
         assert grads[3].abs().max().item() <= 1e-6 * grads[2].abs().max().item()
+
+
+def _agcn_oracle_leaves(gp):
+    leaves = {"PA": gp.PA, "down_w": gp.down_w, "down_b": gp.down_b, "bn_w": gp.bn.weight, "bn_b": gp.bn.bias,
+              "dbn_w": gp.down_bn.weight, "dbn_b": gp.down_bn.bias}
+    for i in range(gp.num_subset):
+        leaves.update({f"a_w{i}": gp.conv_a_w[i], f"a_b{i}": gp.conv_a_b[i], f"b_w{i}": gp.conv_b_w[i],
+                       f"b_b{i}": gp.conv_b_b[i], f"d_w{i}": gp.conv_d_w[i], f"d_b{i}": gp.conv_d_b[i]})
+    for t in leaves.values():
+        t.requires_grad_(True)
+    return leaves
+
+
+def _agcn_module_grads(gcn):
+    g = {"PA": gcn.PA.grad, "down_w": gcn.down[0].weight.grad.flatten(1), "down_b": gcn.down[0].bias.grad,
+         "bn_w": gcn.bn.weight.grad, "bn_b": gcn.bn.bias.grad, "dbn_w": gcn.down[1].weight.grad,
+         "dbn_b": gcn.down[1].bias.grad}
+    for i in range(gcn.num_subset):
+        g.update({f"a_w{i}": gcn.conv_a[i].weight.grad.flatten(1), f"a_b{i}": gcn.conv_a[i].bias.grad,
+                  f"b_w{i}": gcn.conv_b[i].weight.grad.flatten(1), f"b_b{i}": gcn.conv_b[i].bias.grad,
+                  f"d_w{i}": gcn.conv_d[i].weight.grad.flatten(1), f"d_b{i}": gcn.conv_d[i].bias.grad})
+    return g
+
+
+def _compare_grads(got, ref, rel):
+    """Every gradient within rel*max|ref| of its tensor.  Three bias gradients are structurally zero — conv_a's (a bias
+    on `a` shifts every column of the Gram matrix by a constant, which soft-max over that column ignores), conv_d's
+    and down's (a bias in front of a batch-statistics BatchNorm): both sides are rounding noise there, so those are
+    held against the scale of the matching weight gradient instead."""
+    bad = []
+    for k in sorted(ref):
+        g, r = got[k].reshape(ref[k].shape).double().cpu(), ref[k].double().cpu()
+        assert torch.isfinite(g).all(), f"d{k}: non-finite gradient"
+        scale = r.abs().max().item()
+        if k.startswith("a_b") or k.startswith("d_b"):       # (d_b, down_b: a bias in front of a batch-statistics
+            scale = max(scale, ref[k[0] + "_w" + k[3:]].abs().max().item())   # BatchNorm has zero gradient as well)
+        if k == "down_b":
+            scale = max(scale, ref["down_w"].abs().max().item())
+        err = (g - r).abs().max().item()
+        if err > rel * max(scale, 1e-30):
+            bad.append(f"d{k}: err {err:.3e} vs {rel:g}*{scale:.3e}")
+    assert not bad, "; ".join(bad)
+
+
+@pytest.mark.parametrize("N,T,V,cout", [(3, 20, 22, 128), (2, 50, 22, 128), (2, 12, 46, 128), (2, 9, 25, 64), (1, 7, 22, 256)])
+def test_unit_agcn_backward_vs_oracle(N, T, V, cout, dev):
+    """Every parameter gradient of the training-mode graph conv against autograd through the fp64 oracle."""
+    from oracle import stgcn_oracle as so
+    gcn, _, gp, _, gen = _random_stem(V, None, 1000 + T + V + cout, dev, c=cout)
+    gp = gp.to(torch.float64)
+    leaves = _agcn_oracle_leaves(gp)
+    x = torch.randn(N, 3, T, V, generator=gen)
+    yr = so.agcn_forward(x.double(), gp, training=True)
+    G = _kink_free_cotangent(yr, gen)
+    names = sorted(leaves)
+    ref = dict(zip(names, torch.autograd.grad((yr * G.double()).sum(), [leaves[k] for k in names])))
+    gcn.train()
+    y = gcn(x.to(dev))
+    parity_gate(y.detach(), yr.detach(), 1e-4, "training-mode forward")
+    (y * G.to(dev)).sum().backward()
+    _compare_grads(_agcn_module_grads(gcn), ref, 1e-4)
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "f32_valu"])
+def test_stem_training_step_vs_oracle(math, dev):
+    """loss.backward() through tcn0(gcn0(x)) in .train() (train_sttran.py:185-191): all 4,780 + 147,840 parameter
+    gradients against autograd through the fp64 oracle, and the running statistics both BatchNorm layers keep."""
+    from stgcn_amd import set_math_mode
+    from stgcn_amd.graphs import SHREGraph
+    from oracle import stgcn_oracle as so
+    A = torch.from_numpy(SHREGraph("spatial").A.astype(np.float32))
+    gcn, tcn, gp, tp, gen = _random_stem(22, A, 1200, dev)
+    set_math_mode(tcn, math)
+    gp, tp = gp.to(torch.float64), tp.to(torch.float64)
+    leaves = _agcn_oracle_leaves(gp)
+    tleaves = {"t_w": tp.conv_w, "t_b": tp.conv_b, "t_bn_w": tp.bn.weight, "t_bn_b": tp.bn.bias}
+    for t in tleaves.values():
+        t.requires_grad_(True)
+    leaves.update(tleaves)
+    x = torch.randn(4, 3, 40, 22, generator=gen)
+    aux = {}
+    hr = so.agcn_forward(x.double(), gp, training=True)
+    zr = so.tcn_forward(hr, tp, training=True, aux=aux)
+    # cotangent free of both ReLU kinks: the output's and (through a mask on nothing — h feeds a conv) the inner one is
+    # handled by keeping clips whose inner activations stay clear of zero at fp32 resolution
+    G = _kink_free_cotangent(zr, gen)
+    names = sorted(leaves)
+    ref = dict(zip(names, torch.autograd.grad((zr * G.double()).sum(), [leaves[k] for k in names])))
+    gcn.train(); tcn.train()
+    z = tcn(gcn(x.to(dev)))
+    parity_gate(z.detach(), zr.detach(), 1e-4, "training-mode stem forward")
+    (z * G.to(dev)).sum().backward()
+    got = _agcn_module_grads(gcn)
+    got.update({"t_w": tcn.conv.weight.grad.flatten(1).reshape(128, 128, 9), "t_bn_w": tcn.bn.weight.grad,
+                "t_bn_b": tcn.bn.bias.grad})
+    # the inner ReLU (h = relu(...)) cannot be masked out of the loss: a flipped bit there moves gradients by a finite
+    # amount, so the gate for this whole-stem test is 2e-3 of max|ref| (the per-module tests above hold 1e-4)
+    ref.pop("t_b")
+    _compare_grads(got, ref, 2e-3)
+    parity_gate(tcn.bn.running_mean, aux["bn"]["running_mean"], 1e-4, "tcn running_mean")

@@ -11,7 +11,7 @@
 //   * at the end of the clip: dPA += dP ;  soft-max backward  dS = Q*(dP - colsum(Q*dP))/(inter_c*T), Q = P - A_eff ;
 //     dM_s[k,l] += sum_{t,v,w} x~[k,t,v]*dS_s[v,w]*x~[l,t,w]   (x~ = [x;1]: the 4x4 bilinear form the forward folds the
 //     two embeddings into, M_s = Wa~_s^T Wb~_s)
-// and a last tiny kernel sums the per-workgroup partials in a fixed order and maps dM to dWa, dba, dWb, dbb.
+// and two tiny kernels sum the per-workgroup partials in a fixed order and map dM to dWa, dba, dWb, dbb.
 #include "common.h"
 
 namespace stgcn {
@@ -19,42 +19,49 @@ namespace stgcn {
 namespace {
 
 constexpr int PXMAX = 256;   // pixels per frame chunk
-constexpr int DPITCH = PXMAX + 1;
+constexpr int DP = 260;      // row pitch of the dz tiles: 16-byte aligned rows, 8 consecutive rows on distinct banks
+constexpr int NTB = 512;     // threads per workgroup
+constexpr int NCST = 12;     // per-channel constants (10 used)
 
 struct BnRef {
     const float *z, *scale, *shift, *mean, *invstd, *coef;   // coef: [gamma*invstd | mean(g) | mean(g*xhat)] x C
 };
 
 template <int CIN, int S, int NOB>
-__global__ __launch_bounds__(256) void agcn_bwd_kernel(
+__global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
     const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ A_eff, BnRef m, BnRef d,
     const float *__restrict__ dy, const float *__restrict__ Wd, float *__restrict__ part_w /* [grid][Cout][WCOLS] */,
     float *__restrict__ part_pa /* [grid][S][V][V] */, float *__restrict__ part_m /* [grid][S][C1][C1] */, int N, int Cout,
     int T, int V, int inter_c, int TF) {
     constexpr int SC = S * CIN, C1 = CIN + 1;
     constexpr int WCOLS = SC + 1 + CIN + 1;          // per output channel: dWd (SC), dbd, dWdown (CIN), dbdown
-    constexpr int MAINF = SC + 1;                    // main features + constant 1
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int VV = V * V;
-    float *Ps = sm;                                  // [S][V][V]  P of the clip
-    float *dPs = Ps + S * VV;                        // [S][V][V]  dP, later dS
-    float *Xs = dPs + S * VV;                        // [CIN][PXMAX]
+    float *Dm = sm;                                  // [32][DP] dzm of the channel block   (16-byte aligned rows)
+    float *Dd = Dm + 32 * DP;                        // [32][DP] dzd
+    float *Xs = Dd + 32 * DP;                        // [CIN][PXMAX]
     float *Fs = Xs + CIN * PXMAX;                    // [SC][PXMAX] u_s
     float *DUs = Fs + SC * PXMAX;                    // [SC][PXMAX] du_s
-    float *Dm = DUs + SC * PXMAX;                    // [32][DPITCH] dzm of the channel block
-    float *Dd = Dm + 32 * DPITCH;                    // [32][DPITCH] dzd
-    float *Wl = Dd + 32 * DPITCH;                    // [Cout][SC]   Wd re-ordered: Wl[o][s*CIN+k]
-    float *red = Wl + Cout * SC;                     // [4][S*C1*C1] block reduction of dM
+    float *cst = DUs + SC * PXMAX;                   // [Cout][NCST] per-channel constants of the two BatchNorm backward maps
+    float *red = cst + Cout * NCST;                  // [8][S*C1*C1] block reduction of dM
+    float *Ps = red + 8 * S * C1 * C1;               // [S][V][V]  P of the clip
+    float *dPs = Ps + S * VV;                        // [S][V][V]  dP, later dS
     const size_t plane = (size_t)T * V;
 
-    for (int e = tid; e < Cout * SC; e += 256) {
-        const int o = e / SC, f = e - o * SC, s = f / CIN, k = f - s * CIN;
-        Wl[e] = Wd[((size_t)s * Cout + o) * CIN + k];
+    // pre = (sm*zm + tm) + (sd*zd + td) ;  dzm = am*g + bm*zm + cm ;  dzd = ad*g + bd*zd + cd     (g = dy where pre > 0)
+    for (int c = tid; c < Cout; c += NTB) {
+        float *q = cst + c * NCST;
+        const float km = m.coef[c], c1 = m.coef[Cout + c], c2m = m.coef[2 * Cout + c], im = m.invstd[c];
+        const float kd = d.coef[c], c2d = d.coef[2 * Cout + c], id = d.invstd[c];
+        q[0] = m.scale[c]; q[1] = d.scale[c]; q[2] = m.shift[c]; q[9] = d.shift[c];
+        q[3] = km; q[4] = -km * im * c2m; q[5] = km * (im * c2m * m.mean[c] - c1);
+        q[6] = kd; q[7] = -kd * id * c2d; q[8] = kd * (id * c2d * d.mean[c] - c1);
     }
-    float accw[NOB][3];                              // this thread's slice of part_w: (channel tid>>3 of block ob) x 3 columns
+    float accw[NOB];                                 // column (tid & 15) of channel (tid >> 4) of block ob in part_w
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) accw[ob][0] = accw[ob][1] = accw[ob][2] = 0.f;
+    for (int ob = 0; ob < NOB; ++ob) accw[ob] = 0.f;
     float accm[S][C1][C1];
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -62,26 +69,25 @@ __global__ __launch_bounds__(256) void agcn_bwd_kernel(
         for (int k = 0; k < C1; ++k)
 #pragma unroll
             for (int l = 0; l < C1; ++l) accm[s][k][l] = 0.f;
-    const int ol = tid >> 3, fg = tid & 7;           // phase (b): channel within the block, feature group
+    const int ol = tid >> 4, col = tid & 15;         // phase (b): channel within the block, column of part_w
+    const int pa = tid & 255, half = tid >> 8;       // phase (a): pixel, half of the block's 32 channels
     float *my_pa = part_pa + (size_t)blockIdx.x * S * VV;
-    for (int e = tid; e < S * VV; e += 256) my_pa[e] = 0.f;
+    for (int e = tid; e < S * VV; e += NTB) my_pa[e] = 0.f;
 
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         __syncthreads();
         const float *Pn = P + (size_t)n * S * VV;
-        for (int e = tid; e < S * VV; e += 256) { Ps[e] = Pn[e]; dPs[e] = 0.f; }
+        for (int e = tid; e < S * VV; e += NTB) { Ps[e] = Pn[e]; dPs[e] = 0.f; }
         const float *xn = x + (size_t)n * CIN * plane;
         for (int t0 = 0; t0 < T; t0 += TF) {
             const int px = min(TF, T - t0) * V;
             __syncthreads();
-            for (int e = tid; e < CIN * px; e += 256) {
+            for (int e = tid; e < CIN * px; e += NTB) {
                 const int k = e / px, p = e - k * px;
                 Xs[k * PXMAX + p] = xn[(size_t)k * plane + (size_t)t0 * V + p];
             }
+            for (int e = tid; e < SC * PXMAX; e += NTB) DUs[e] = 0.f;
             __syncthreads();
-            float du[SC];
-#pragma unroll
-            for (int f = 0; f < SC; ++f) du[f] = 0.f;
             if (tid < px) {                          // u_s[k] of this thread's pixel (model/unit_agcn.py:87-88)
                 const int tt = tid / V, w = tid - tt * V;
                 float u[SC];
@@ -98,51 +104,70 @@ __global__ __launch_bounds__(256) void agcn_bwd_kernel(
 #pragma unroll
                 for (int f = 0; f < SC; ++f) Fs[f * PXMAX + tid] = u[f];
             }
+            float du[SC];
+#pragma unroll
+            for (int f = 0; f < SC; ++f) du[f] = 0.f;
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) {
                 __syncthreads();                     // Fs complete / previous block consumed
-                // rebuild dzm, dzd of channels ob*32 .. +31 for the chunk's pixels
-                for (int e = tid; e < 32 * px; e += 256) {
-                    const int r = e / px, p = e - r * px, c = ob * 32 + r;
-                    const size_t g = ((size_t)n * Cout + c) * plane + (size_t)t0 * V + p;
-                    const float zm = m.z[g], zd = d.z[g];
-                    const float pre = fmaf(zm, m.scale[c], m.shift[c]) + fmaf(zd, d.scale[c], d.shift[c]);
-                    const float gg = pre > 0.f ? dy[g] : 0.f;
-                    Dm[r * DPITCH + p] = m.coef[c] * (gg - m.coef[Cout + c] - (zm - m.mean[c]) * m.invstd[c] * m.coef[2 * Cout + c]);
-                    Dd[r * DPITCH + p] = d.coef[c] * (gg - d.coef[Cout + c] - (zd - d.mean[c]) * d.invstd[c] * d.coef[2 * Cout + c]);
+                // rebuild dzm, dzd of channels ob*32 .. +31: wave w owns rows 4w .. 4w+3, lanes stride the pixels
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = wave * 4 + rr, c = ob * 32 + r;
+                    const float *q = cst + c * NCST;
+                    const float s_m = q[0], s_d = q[1], t_m = q[2], t_d = q[9], am = q[3], bm = q[4], cm = q[5], ad = q[6], bd = q[7],
+                                cd = q[8];
+                    const size_t g0 = ((size_t)n * Cout + c) * plane + (size_t)t0 * V;
+                    for (int p = lane; p < px; p += 64) {
+                        const float zm = m.z[g0 + p], zd = d.z[g0 + p];
+                        const float gg = fmaf(zm, s_m, t_m) + fmaf(zd, s_d, t_d) > 0.f ? dy[g0 + p] : 0.f;   // the forward's own expression
+                        Dm[r * DP + p] = fmaf(am, gg, fmaf(bm, zm, cm));
+                        Dd[r * DP + p] = fmaf(ad, gg, fmaf(bd, zd, cd));
+                    }
                 }
                 __syncthreads();
-                if (tid < px) {                      // (a) du_s[k] += Wd_s[o][k] * dzm[o]
-                    for (int r = 0; r < 32; ++r) {
-                        const float dv = Dm[r * DPITCH + tid];
-                        const float *wr = Wl + (ob * 32 + r) * SC;
+                if (pa < px) {                       // (a) du_s[k] += Wd_s[o][k] * dzm[o], this half's 16 channels
+                    for (int r = half * 16; r < half * 16 + 16; ++r) {
+                        const float dv = Dm[r * DP + pa];
+                        const int o = ob * 32 + r;   // (wave-uniform: the weights come through scalar loads)
 #pragma unroll
-                        for (int f = 0; f < SC; ++f) du[f] = fmaf(wr[f], dv, du[f]);
+                        for (int s = 0; s < S; ++s)
+#pragma unroll
+                            for (int k = 0; k < CIN; ++k)
+                                du[s * CIN + k] = fmaf(Wd[((size_t)s * Cout + o) * CIN + k], dv, du[s * CIN + k]);
                     }
                 }
-                {                                    // (b) weight / bias gradients of channel ob*32 + ol
-                    const float *dmr = Dm + ol * DPITCH, *ddr = Dd + ol * DPITCH;
-                    const int f0 = fg, f1 = fg + 8;  // main columns (feature SC is the constant 1 = bias)
-                    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-                    for (int p = 0; p < px; ++p) {
-                        const float dm = dmr[p], dd = ddr[p];
-                        a0 = fmaf(dm, f0 < SC ? Fs[f0 * PXMAX + p] : 1.f, a0);
-                        if (f1 < MAINF) a1 = fmaf(dm, f1 < SC ? Fs[f1 * PXMAX + p] : 1.f, a1);
-                        if (fg <= CIN) a2 = fmaf(dd, fg < CIN ? Xs[fg * PXMAX + p] : 1.f, a2);
+                if (col < WCOLS) {                   // (b) column `col` of channel ob*32 + ol
+                    const bool main_side = col <= SC;
+                    const float *dr = (main_side ? Dm : Dd) + ol * DP;
+                    const bool is_bias = col == SC || col == WCOLS - 1;
+                    const float *fr = col < SC ? Fs + col * PXMAX : Xs + (is_bias ? 0 : col - SC - 1) * PXMAX;
+                    float a = 0.f;
+                    const int px4 = px & ~3;
+                    if (is_bias) {
+                        for (int p = 0; p < px4; p += 4) {
+                            const float4 dq = *reinterpret_cast<const float4 *>(dr + p);
+                            a += (dq.x + dq.y) + (dq.z + dq.w);
+                        }
+                        for (int p = px4; p < px; ++p) a += dr[p];
+                    } else {
+                        for (int p = 0; p < px4; p += 4) {
+                            const float4 dq = *reinterpret_cast<const float4 *>(dr + p);
+                            const float4 fq = *reinterpret_cast<const float4 *>(fr + p);
+                            a = fmaf(dq.x, fq.x, fmaf(dq.y, fq.y, fmaf(dq.z, fq.z, fmaf(dq.w, fq.w, a))));
+                        }
+                        for (int p = px4; p < px; ++p) a = fmaf(dr[p], fr[p], a);
                     }
-                    accw[ob][0] += a0;
-                    accw[ob][1] += a1;
-                    accw[ob][2] += a2;
+                    accw[ob] += a;
                 }
             }
-            __syncthreads();
-            if (tid < px) {
+            if (pa < px) {                           // the two halves' du (a + b: order-independent)
 #pragma unroll
-                for (int f = 0; f < SC; ++f) DUs[f * PXMAX + tid] = du[f];
+                for (int f = 0; f < SC; ++f) atomicAdd(&DUs[f * PXMAX + pa], du[f]);
             }
             __syncthreads();
             const int tf = px / V;
-            for (int e = tid; e < S * VV; e += 256) {  // dP_s[v][w] += sum_{k,t} x[k,t,v] * du_s[k,t,w]
+            for (int e = tid; e < S * VV; e += NTB) {  // dP_s[v][w] += sum_{k,t} x[k,t,v] * du_s[k,t,w]
                 const int s = e / VV, vw = e - s * VV, v = vw / V, w = vw - v * V;
                 float a = 0.f;
                 for (int tt = 0; tt < tf; ++tt)
@@ -153,11 +178,11 @@ __global__ __launch_bounds__(256) void agcn_bwd_kernel(
             }
         }
         __syncthreads();
-        for (int e = tid; e < S * VV; e += 256) my_pa[e] += dPs[e];   // PA enters P additively (unit_agcn.py:76,85)
+        for (int e = tid; e < S * VV; e += NTB) my_pa[e] += dPs[e];   // PA enters P additively (unit_agcn.py:76,85)
         __syncthreads();
         // soft-max backward over v (dim -2), one thread per column (s, w)
         const float denom = (float)(inter_c * T);
-        for (int e = tid; e < S * V; e += 256) {
+        for (int e = tid; e < S * V; e += NTB) {
             const int s = e / V, w = e - s * V;
             float dot = 0.f;
             for (int v = 0; v < V; ++v) {
@@ -173,12 +198,12 @@ __global__ __launch_bounds__(256) void agcn_bwd_kernel(
         for (int t0 = 0; t0 < T; t0 += TF) {
             const int px = min(TF, T - t0) * V;
             __syncthreads();
-            for (int e = tid; e < CIN * px; e += 256) {
+            for (int e = tid; e < CIN * px; e += NTB) {
                 const int k = e / px, p = e - k * px;
                 Xs[k * PXMAX + p] = xn[(size_t)k * plane + (size_t)t0 * V + p];
             }
             __syncthreads();
-            for (int it = tid; it < S * px; it += 256) {
+            for (int it = tid; it < S * px; it += NTB) {
                 const int s = it / px, p = it - s * px, tt = p / V, v = p - tt * V;
                 float r[C1];
 #pragma unroll
@@ -208,15 +233,11 @@ __global__ __launch_bounds__(256) void agcn_bwd_kernel(
 
     // ---- partials of this workgroup ------------------------------------------------------------
     float *my_w = part_w + (size_t)blockIdx.x * Cout * WCOLS;
+    if (col < WCOLS) {
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-        float *row = my_w + (size_t)(ob * 32 + ol) * WCOLS;
-        row[fg] = accw[ob][0];                                   // main column fg (fg < 8 <= SC)
-        if (fg + 8 < MAINF) row[fg + 8] = accw[ob][1];           // main columns 8 .. SC (SC = bias)
-        if (fg <= CIN) row[MAINF + fg] = accw[ob][2];            // down columns
+        for (int ob = 0; ob < NOB; ++ob) my_w[(size_t)(ob * 32 + ol) * WCOLS + col] = accw[ob];
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -228,44 +249,52 @@ __global__ __launch_bounds__(256) void agcn_bwd_kernel(
                 if (lane == 0) red[wave * S * C1 * C1 + (s * C1 + k) * C1 + l] = v;
             }
     __syncthreads();
-    if (tid < S * C1 * C1)
-        part_m[(size_t)blockIdx.x * S * C1 * C1 + tid] =
-            red[tid] + red[S * C1 * C1 + tid] + red[2 * S * C1 * C1 + tid] + red[3 * S * C1 * C1 + tid];
+    if (tid < S * C1 * C1) {
+        float v = 0.f;
+        for (int w8 = 0; w8 < 8; ++w8) v += red[w8 * S * C1 * C1 + tid];
+        part_m[(size_t)blockIdx.x * S * C1 * C1 + tid] = v;
+    }
 }
 
-// Sums the partials in a fixed order and maps them to the parameter gradients.  One workgroup.
+// Sums the per-workgroup partials in a fixed order: one thread per output element.
+//   out_w [Cout][WCOLS] -> dWd (S,Cout,CIN), dbd (S,Cout), dWdown (Cout,CIN), dbdown (Cout);  dPA;  dM -> dm_out
 template <int CIN, int S>
-__global__ __launch_bounds__(256) void agcn_bwd_final_kernel(
+__global__ __launch_bounds__(256) void agcn_bwd_reduce_kernel(
     const float *__restrict__ part_w, const float *__restrict__ part_pa, const float *__restrict__ part_m, int parts,
-    const float *__restrict__ Wa, const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
-    float *__restrict__ dWa, float *__restrict__ dba, float *__restrict__ dWb, float *__restrict__ dbb,
     float *__restrict__ dWd, float *__restrict__ dbd, float *__restrict__ dWdown, float *__restrict__ dbdown,
-    float *__restrict__ dPA, int Cout, int V, int inter_c) {
+    float *__restrict__ dPA, float *__restrict__ dm_out, int Cout, int V) {
     constexpr int SC = S * CIN, C1 = CIN + 1, WCOLS = SC + 1 + CIN + 1, MAINF = SC + 1;
-    __shared__ float dM[S * C1 * C1];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < Cout * WCOLS; e += 256) {
+    const int nw = Cout * WCOLS, npa = S * V * V, nm = S * C1 * C1;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < nw) {
         float s = 0.f;
-        for (int p = 0; p < parts; ++p) s += part_w[(size_t)p * Cout * WCOLS + e];
+        for (int p = 0; p < parts; ++p) s += part_w[(size_t)p * nw + e];
         const int o = e / WCOLS, c = e - o * WCOLS;
         if (c < SC) dWd[((size_t)(c / CIN) * Cout + o) * CIN + (c % CIN)] = s;
         else if (c == SC) { for (int q = 0; q < S; ++q) dbd[q * Cout + o] = s; }   // every bd_s adds straight into zm
         else if (c < MAINF + CIN) dWdown[o * CIN + (c - MAINF)] = s;
         else dbdown[o] = s;
-    }
-    for (int e = tid; e < S * V * V; e += 256) {
+    } else if (e < nw + npa) {
+        const int i = e - nw;
         float s = 0.f;
-        for (int p = 0; p < parts; ++p) s += part_pa[(size_t)p * S * V * V + e];
-        dPA[e] = s;
-    }
-    if (tid < S * C1 * C1) {
+        for (int p = 0; p < parts; ++p) s += part_pa[(size_t)p * npa + i];
+        dPA[i] = s;
+    } else if (e < nw + npa + nm) {
+        const int i = e - nw - npa;
         float s = 0.f;
-        for (int p = 0; p < parts; ++p) s += part_m[(size_t)p * S * C1 * C1 + tid];
-        dM[tid] = s;
+        for (int p = 0; p < parts; ++p) s += part_m[(size_t)p * nm + i];
+        dm_out[i] = s;
     }
-    __syncthreads();
-    // M_s[k][l] = sum_c Wa~_s[c][k] * Wb~_s[c][l]   =>   dWa~[c][k] = sum_l dM[k][l] Wb~[c][l],  dWb~[c][l] = sum_k dM[k][l] Wa~[c][k]
-    for (int e = tid; e < S * inter_c * C1; e += 256) {
+}
+
+// M_s[k][l] = sum_c Wa~_s[c][k] * Wb~_s[c][l]  =>  dWa~[c][k] = sum_l dM[k][l] Wb~[c][l],  dWb~[c][l] = sum_k dM[k][l] Wa~[c][k]
+template <int CIN, int S>
+__global__ __launch_bounds__(256) void agcn_bwd_embed_kernel(
+    const float *__restrict__ dM, const float *__restrict__ Wa, const float *__restrict__ ba, const float *__restrict__ Wb,
+    const float *__restrict__ bb, float *__restrict__ dWa, float *__restrict__ dba, float *__restrict__ dWb,
+    float *__restrict__ dbb, int inter_c) {
+    constexpr int C1 = CIN + 1;
+    for (int e = threadIdx.x; e < S * inter_c * C1; e += 256) {
         const int s = e / (inter_c * C1), rc = e - s * inter_c * C1, c = rc / C1, j = rc - c * C1;
         const int row = s * inter_c + c;
         float ga = 0.f, gb = 0.f;
@@ -293,8 +322,8 @@ inline AgcnBwdPlan plan_agcn_bwd(int N, int Cin, int Cout, int T, int V, int S) 
     const int SC = S * Cin, C1 = Cin + 1;
     int TF = PXMAX / V;
     if (TF > T) TF = T;
-    const size_t fl = (size_t)2 * S * V * V + (size_t)(Cin + 2 * SC) * PXMAX + (size_t)2 * 32 * DPITCH + (size_t)Cout * SC +
-                      (size_t)4 * S * C1 * C1;
+    const size_t fl = (size_t)2 * 32 * DP + (size_t)(Cin + 2 * SC) * PXMAX + (size_t)Cout * NCST + (size_t)8 * S * C1 * C1 +
+                      (size_t)2 * S * V * V;
     pl.lds = fl * 4;
     if (pl.lds > (size_t)kLdsBytes) return pl;
     pl.TF = TF;
@@ -307,12 +336,13 @@ inline AgcnBwdPlan plan_agcn_bwd(int N, int Cin, int Cout, int T, int V, int S) 
 
 bool agcn_bwd_supported(int N, int Cin, int Cout, int T, int V, int S) { return plan_agcn_bwd(N, Cin, Cout, T, V, S).ok; }
 
-// partials: [grid][Cout][WCOLS] + [grid][S][V][V] + [grid][S][C1][C1] floats
+// partials: [grid][Cout][WCOLS] + [grid][S][V][V] + [grid][S][C1][C1] floats, then the summed dM (S*C1*C1)
 size_t agcn_bwd_part_bytes(int N, int Cin, int Cout, int T, int V, int S) {
     const AgcnBwdPlan pl = plan_agcn_bwd(N, Cin, Cout, T, V, S);
     if (!pl.ok) return 0;
     const int C1 = Cin + 1, WCOLS = S * Cin + 1 + Cin + 1;
-    return (size_t)pl.grid * ((size_t)Cout * WCOLS + (size_t)S * V * V + (size_t)S * C1 * C1) * sizeof(float);
+    return ((size_t)pl.grid * ((size_t)Cout * WCOLS + (size_t)S * V * V + (size_t)S * C1 * C1) + (size_t)S * C1 * C1) *
+           sizeof(float);
 }
 
 // m_* / d_*: z, scale, shift, mean, invstd, coef of the main / down BatchNorm (coef from launch_bn_bwd_finalize)
@@ -327,11 +357,12 @@ int launch_agcn_bwd(const float *x, const float *P, const float *A_eff, const fl
                     Cin, S, Cout, V);
     const int C1 = Cin + 1, WCOLS = S * Cin + 1 + Cin + 1;
     float *part_w = part, *part_pa = part_w + (size_t)pl.grid * Cout * WCOLS, *part_m = part_pa + (size_t)pl.grid * S * V * V;
+    float *dm_sum = part_m + (size_t)pl.grid * S * C1 * C1;
     const BnRef m{m_[0], m_[1], m_[2], m_[3], m_[4], m_[5]}, d{d_[0], d_[1], d_[2], d_[3], d_[4], d_[5]};
 #define LAUNCH_BWD(NOB)                                                                                          \
     do {                                                                                                         \
         STGCN_HIP_CHECK(allow_lds((agcn_bwd_kernel<3, 3, NOB>), pl.lds));                                        \
-        hipLaunchKernelGGL((agcn_bwd_kernel<3, 3, NOB>), dim3(pl.grid), dim3(256), pl.lds, st, x, P, A_eff, m, d, dy, \
+        hipLaunchKernelGGL((agcn_bwd_kernel<3, 3, NOB>), dim3(pl.grid), dim3(NTB), pl.lds, st, x, P, A_eff, m, d, dy, \
                            Wd, part_w, part_pa, part_m, N, Cout, T, V, inter_c, pl.TF);                          \
     } while (0)
     if (Cout == 64) LAUNCH_BWD(2);
@@ -339,10 +370,13 @@ int launch_agcn_bwd(const float *x, const float *P, const float *A_eff, const fl
     else LAUNCH_BWD(8);
 #undef LAUNCH_BWD
     STGCN_LAUNCH_CHECK("agcn_bwd_kernel");
-    hipLaunchKernelGGL((agcn_bwd_final_kernel<3, 3>), dim3(1), dim3(256), 0, st, part_w, part_pa, part_m, pl.grid, Wa, ba,
-                       Wb, bb, dWa, dba, dWb, dbb, dWd, dbd, dWdown, dbdown, dPA, Cout, V, inter_c);
-    STGCN_LAUNCH_CHECK("agcn_bwd_final_kernel");
-    (void)C1;
+    const int total = Cout * WCOLS + S * V * V + S * C1 * C1;
+    hipLaunchKernelGGL((agcn_bwd_reduce_kernel<3, 3>), dim3(ceil_div(total, 256)), dim3(256), 0, st, part_w, part_pa, part_m,
+                       pl.grid, dWd, dbd, dWdown, dbdown, dPA, dm_sum, Cout, V);
+    STGCN_LAUNCH_CHECK("agcn_bwd_reduce_kernel");
+    hipLaunchKernelGGL((agcn_bwd_embed_kernel<3, 3>), dim3(1), dim3(256), 0, st, dm_sum, Wa, ba, Wb, bb, dWa, dba, dWb, dbb,
+                       inter_c);
+    STGCN_LAUNCH_CHECK("agcn_bwd_embed_kernel");
     return STGCN_OK;
 }
 

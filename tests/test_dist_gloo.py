@@ -87,3 +87,48 @@ def test_shard_bounds_properties():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_bounds(4, 2, 2)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, "st-gcn-altformer_amd"))
+    torch.set_num_threads(1)
+    from stgcn_amd import dist as sd
+    sd.init("gloo")
+    torch.manual_seed(5)                                   # same weights on both ranks, rank-dependent gradients
+    a, b = torch.nn.Conv2d(3, 8, (9, 1)), torch.nn.BatchNorm2d(8)
+    for i, p in enumerate(list(a.parameters()) + list(b.parameters())):
+        p.grad = torch.full_like(p, float(rank + 1)) * (i + 1) + torch.arange(p.numel(), dtype=torch.float32).view_as(p) * rank
+    b.bias.grad = None                                     # a parameter without gradient is skipped, not zero-filled
+    n = sd.all_reduce_grads([a, b])
+    sd.barrier()
+    q.put((rank, n, [None if p.grad is None else p.grad.numpy() for p in list(a.parameters()) + list(b.parameters())]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce():
+    """One flat-bucket all-reduce leaves every rank with the mean of the ranks' gradients (the DDP exchange of the
+    training step)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shapes = [(8, 3, 9, 1), (8,), (8,), (8,)]
+    assert res[0][1] == res[1][1] == 8 * 27 + 8 + 8
+    for i, shp in enumerate(shapes):
+        g0, g1 = res[0][2][i], res[1][2][i]
+        if i == 3:
+            assert g0 is None and g1 is None
+            continue
+        n = 1
+        for d in shp:
+            n *= d
+        ar = torch.arange(n, dtype=torch.float32).view(shp)
+        want = (1.0 * (i + 1) + 2.0 * (i + 1) + ar) / 2          # mean of rank 0 and rank 1
+        assert torch.allclose(torch.from_numpy(g0), want) and torch.allclose(torch.from_numpy(g1), want)

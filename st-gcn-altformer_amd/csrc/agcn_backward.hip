@@ -107,6 +107,23 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
             float du[SC];
 #pragma unroll
             for (int f = 0; f < SC; ++f) du[f] = 0.f;
+            // the three full-size operands of a channel block travel HBM -> registers one block ahead of their use
+            // (12 independent loads per lane in flight; fetched in place, the tile build was a chain of load round trips)
+            float rzm[4][PXMAX / 64], rzd[4][PXMAX / 64], rdy[4][PXMAX / 64];
+            auto prefetch = [&](int ob) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const size_t g0 = ((size_t)n * Cout + ob * 32 + wave * 4 + rr) * plane + (size_t)t0 * V;
+#pragma unroll
+                    for (int i = 0; i < PXMAX / 64; ++i) {
+                        const size_t g = g0 + min(lane + 64 * i, px - 1);
+                        rzm[rr][i] = m.z[g];
+                        rzd[rr][i] = d.z[g];
+                        rdy[rr][i] = dy[g];
+                    }
+                }
+            };
+            prefetch(0);
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) {
                 __syncthreads();                     // Fs complete / previous block consumed
@@ -117,14 +134,18 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
                     const float *q = cst + c * NCST;
                     const float s_m = q[0], s_d = q[1], t_m = q[2], t_d = q[9], am = q[3], bm = q[4], cm = q[5], ad = q[6], bd = q[7],
                                 cd = q[8];
-                    const size_t g0 = ((size_t)n * Cout + c) * plane + (size_t)t0 * V;
-                    for (int p = lane; p < px; p += 64) {
-                        const float zm = m.z[g0 + p], zd = d.z[g0 + p];
-                        const float gg = fmaf(zm, s_m, t_m) + fmaf(zd, s_d, t_d) > 0.f ? dy[g0 + p] : 0.f;   // the forward's own expression
-                        Dm[r * DP + p] = fmaf(am, gg, fmaf(bm, zm, cm));
-                        Dd[r * DP + p] = fmaf(ad, gg, fmaf(bd, zd, cd));
+#pragma unroll
+                    for (int i = 0; i < PXMAX / 64; ++i) {
+                        const int p = lane + 64 * i;
+                        const float zm = rzm[rr][i], zd = rzd[rr][i];
+                        const float gg = fmaf(zm, s_m, t_m) + fmaf(zd, s_d, t_d) > 0.f ? rdy[rr][i] : 0.f;   // the forward's own expression
+                        if (p < px) {
+                            Dm[r * DP + p] = fmaf(am, gg, fmaf(bm, zm, cm));
+                            Dd[r * DP + p] = fmaf(ad, gg, fmaf(bd, zd, cd));
+                        }
                     }
                 }
+                if (ob + 1 < NOB) prefetch(ob + 1);
                 __syncthreads();
                 if (pa < px) {                       // (a) du_s[k] += Wd_s[o][k] * dzm[o], this half's 16 channels
                     for (int r = half * 16; r < half * 16 + 16; ++r) {

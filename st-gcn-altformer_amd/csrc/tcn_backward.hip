@@ -238,7 +238,7 @@ constexpr int TFM_MAX = 4;   // output frames per unit (the plan picks 4, 2 or 1
 constexpr int KHMAX = 5;     // taps per wave
 constexpr int WG_THREADS = 512;
 
-template <int TERMS>
+template <int TERMS, int UB /* B units per thread: 3 or 5 */>
 __global__ __launch_bounds__(WG_THREADS) void tcn_wgrad_mfma_kernel(const float *__restrict__ dz, const float *__restrict__ x,
                                                                      float *__restrict__ part, int N, int Cin, int Cout,
                                                                      int T, int V, int K, int Vp, int pitchA, int pitchB,
@@ -248,11 +248,11 @@ __global__ __launch_bounds__(WG_THREADS) void tcn_wgrad_mfma_kernel(const float 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ob = wave & 3, tg = wave >> 2;
     const int KH = (K + 1) / 2;
-    const int k_lo = tg * KH, k_hi = min(K, k_lo + KH);
-    const int pad = (K - 1) / 2;
+    const int k_lo = tg * KH;                     // this wave's taps k_lo .. k_lo+KHMAX-1; those >= K are computed on real
+    const int pad = (K - 1) / 2;                  // (finite) frames and dropped at the end: the tap loop has no branches
     const int c0 = blockIdx.x * 32, o0 = blockIdx.y * 128;
     const int upf = Vp / 8;                       // 8-pixel units per frame
-    const int FRB = TFM + K - 1;                  // input frames per unit
+    const int FRB = TFM + 2 * KHMAX - 1;          // input frames per unit (taps 0 .. 2*KHMAX-1)
     const int unitsA = 128 * TFM * upf, unitsB = 32 * FRB * upf;
     // LDS: A hi | A lo | B hi | B lo    (row pitches in bytes, 16 B x odd)
     char *Ahi = smw, *Alo = Ahi + 128 * pitchA, *Bhi = Alo + 128 * pitchA, *Blo = Bhi + 32 * pitchB;
@@ -265,29 +265,57 @@ __global__ __launch_bounds__(WG_THREADS) void tcn_wgrad_mfma_kernel(const float 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-    // staging: thread handles 8-pixel units e = tid, tid+512, ... of A (3 for V=22) and of B
-    constexpr int UA = 4, UB = 4;                 // max units per thread (host checks unitsA <= UA*512, unitsB <= UB*512)
+    // staging: thread handles the 8-pixel units e = tid, tid+512, ... of A and of B.  All loads are unconditional on
+    // clamped addresses (then zeroed by a select), so the prefetch is a straight run of loads without branches.
+    constexpr int UA = 3;                         // A units per thread (the plan checks unitsA <= UA*512, unitsB <= UB*512)
     float pa[UA][8], pb[UB][8];
+    int a_d[UA], b_d[UB];                         // unit descriptors: row << 16 | frame << 8 | first joint
+#pragma unroll
+    for (int i = 0; i < UA; ++i) {
+        const int e = min(tid + i * WG_THREADS, unitsA - 1);
+        const int row = e / (TFM * upf), q = e - row * TFM * upf, tt = q / upf;
+        a_d[i] = row << 16 | tt << 8 | (q - tt * upf) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+        const int e = min(tid + i * WG_THREADS, unitsB - 1);
+        const int row = e / (FRB * upf), q = e - row * FRB * upf, ff = q / upf;
+        b_d[i] = row << 16 | ff << 8 | (q - ff * upf) * 8;
+    }
+#define D_ROW(d) ((d) >> 16)
+#define D_FR(d) (((d) >> 8) & 0xff)
+#define D_V0(d) ((d) & 0xff)
+    // Loads go through buffer resources (one per operand and clip): a lane needs ONE offset register per 8-pixel unit,
+    // the 8 loads differ in the instruction's immediate offset, and a unit outside the clip (frame < 0 or >= T) is given
+    // an offset past num_records, which the hardware answers with zeros — no branches, no per-load address registers.
+    const unsigned clipA = (unsigned)((size_t)Cout * T * V * 4), clipB = (unsigned)((size_t)Cin * T * V * 4);
+    constexpr unsigned OOB = 0x7ffffff0u;
     auto fetch = [&](int u) {
-        const int n = u / chunks, t0 = (u - n * chunks) * TFM;
+        const int n = __builtin_amdgcn_readfirstlane(u / chunks);
+        const int t0 = (u - n * chunks) * TFM;
+        const __amdgpu_buffer_rsrc_t ra =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dz + (size_t)n * Cout * T * V), 0, clipA, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)n * Cin * T * V), 0, clipB, 0x00020000);
 #pragma unroll
         for (int i = 0; i < UA; ++i) {
-            const int e = tid + i * WG_THREADS;
-            const int row = e / (TFM * upf), q = e - row * TFM * upf, tt = q / upf, v0 = (q - tt * upf) * 8;
-            const bool okr = e < unitsA && t0 + tt < T;
-            const float *src = dz + (((size_t)n * Cout + o0 + row) * T + t0 + tt) * V + v0;
+            const int t = t0 + D_FR(a_d[i]);
+            const unsigned off = t < T ? (unsigned)((((o0 + D_ROW(a_d[i])) * T + t) * V + D_V0(a_d[i])) * 4) : OOB;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pa[i][j] = (okr && v0 + j < V) ? src[j] : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const float val = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, off + 4 * j, 0, 0));
+                pa[i][j] = (D_V0(a_d[i]) + j < V) ? val : 0.f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < UB; ++i) {
-            const int e = tid + i * WG_THREADS;
-            const int row = e / (FRB * upf), q = e - row * FRB * upf, ff = q / upf, v0 = (q - ff * upf) * 8;
-            const int f = t0 - pad + ff;
-            const bool okr = e < unitsB && f >= 0 && f < T;
-            const float *src = x + (((size_t)n * Cin + c0 + row) * T + f) * V + v0;
+            const int f = t0 - pad + D_FR(b_d[i]);
+            const unsigned off = (f >= 0 && f < T) ? (unsigned)((((c0 + D_ROW(b_d[i])) * T + f) * V + D_V0(b_d[i])) * 4) : OOB;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pb[i][j] = (okr && v0 + j < V) ? src[j] : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const float val = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, off + 4 * j, 0, 0));
+                pb[i][j] = (D_V0(b_d[i]) + j < V) ? val : 0.f;
+            }
         }
     };
     auto stash = [&]() {
@@ -295,31 +323,32 @@ __global__ __launch_bounds__(WG_THREADS) void tcn_wgrad_mfma_kernel(const float 
         for (int i = 0; i < UA; ++i) {
             const int e = tid + i * WG_THREADS;
             if (e < unitsA) {
-                const int row = e / (TFM * upf), q = e - row * TFM * upf;
+                const int q = D_FR(a_d[i]) * upf + (D_V0(a_d[i]) >> 3);
                 uint4 hi, lo;
                 split8(pa[i], hi, lo);
-                *reinterpret_cast<uint4 *>(Ahi + row * pitchA + q * 16) = hi;
-                if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(Alo + row * pitchA + q * 16) = lo;
+                *reinterpret_cast<uint4 *>(Ahi + D_ROW(a_d[i]) * pitchA + q * 16) = hi;
+                if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(Alo + D_ROW(a_d[i]) * pitchA + q * 16) = lo;
             }
         }
 #pragma unroll
         for (int i = 0; i < UB; ++i) {
             const int e = tid + i * WG_THREADS;
             if (e < unitsB) {
-                const int row = e / (FRB * upf), q = e - row * FRB * upf;
+                const int q = D_FR(b_d[i]) * upf + (D_V0(b_d[i]) >> 3);
                 uint4 hi, lo;
                 split8(pb[i], hi, lo);
-                *reinterpret_cast<uint4 *>(Bhi + row * pitchB + q * 16) = hi;
-                if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(Blo + row * pitchB + q * 16) = lo;
+                *reinterpret_cast<uint4 *>(Bhi + D_ROW(b_d[i]) * pitchB + q * 16) = hi;
+                if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(Blo + D_ROW(b_d[i]) * pitchB + q * 16) = lo;
             }
         }
     };
 
-    const int ksteps = TFM * Vp / 16;             // host guarantees TFM*Vp % 16 == 0
+    const int ksteps = TFM * Vp / 16;             // the plan guarantees TFM*Vp % 16 == 0
     const int h = lane >> 5;
     const char *arow = Ahi + (ob * 32 + (lane & 31)) * pitchA + h * 16;
-    const char *brow = Bhi + (lane & 31) * pitchB + h * 16;
+    const char *brow = Bhi + (lane & 31) * pitchB + h * 16 + k_lo * Vp * 2;
     const int aoff_lo = 128 * pitchA, boff_lo = 32 * pitchB;
+    const int tapb = Vp * 2;                      // bytes between consecutive taps of a B fragment
 
     int u = blockIdx.z;
     if (u < nunits) fetch(u);
@@ -329,34 +358,47 @@ __global__ __launch_bounds__(WG_THREADS) void tcn_wgrad_mfma_kernel(const float 
         __syncthreads();
         if (u + (int)gridDim.z < nunits) fetch(u + gridDim.z);   // in flight during the MFMAs below
         for (int ks = 0; ks < ksteps; ++ks) {
-            const uint4 ah = *reinterpret_cast<const uint4 *>(arow + ks * 32);
-            uint4 al = ah;
+            // fragment reads of a group of taps first, then its MFMAs (which wait with counted lgkmcnt, in issue order);
+            // two groups (3 + 2 taps) keep the live fragments at 32 registers
+            uint4 ah, al;
+            ah = *reinterpret_cast<const uint4 *>(arow + ks * 32);
+            al = ah;
             if constexpr (TERMS == 3) al = *reinterpret_cast<const uint4 *>(arow + aoff_lo + ks * 32);
-#pragma unroll
-            for (int kk = 0; kk < KHMAX; ++kk) {
-                const int k = k_lo + kk;
-                if (k < k_hi) {
-                    const char *bp = brow + ks * 32 + k * Vp * 2;
-                    const uint4 bh = *reinterpret_cast<const uint4 *>(bp);
-                    if constexpr (TERMS == 3) {
-                        const uint4 bl = *reinterpret_cast<const uint4 *>(bp + boff_lo);
-                        acc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah),
-                                                                          __builtin_bit_cast(bf16x8, bl), acc[kk], 0, 0, 0);
-                        acc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al),
-                                                                          __builtin_bit_cast(bf16x8, bh), acc[kk], 0, 0, 0);
-                    }
-                    acc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah),
-                                                                      __builtin_bit_cast(bf16x8, bh), acc[kk], 0, 0, 0);
-                }
-            }
+#define WGRAD_GROUP(K0, KN)                                                                                          \
+    {                                                                                                                \
+        uint4 bh[KN], bl[KN];                                                                                        \
+        _Pragma("unroll") for (int kk = 0; kk < KN; ++kk) {                                                          \
+            bh[kk] = *reinterpret_cast<const uint4 *>(brow + ks * 32 + (K0 + kk) * tapb);                            \
+            bl[kk] = bh[kk];                                                                                         \
+            if constexpr (TERMS == 3) bl[kk] = *reinterpret_cast<const uint4 *>(brow + boff_lo + ks * 32 + (K0 + kk) * tapb); \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        _Pragma("unroll") for (int kk = 0; kk < KN; ++kk) {                                                          \
+            if constexpr (TERMS == 3) {                                                                              \
+                acc[K0 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah),                \
+                                                                       __builtin_bit_cast(bf16x8, bl[kk]), acc[K0 + kk], 0, 0, 0); \
+                acc[K0 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al),                \
+                                                                       __builtin_bit_cast(bf16x8, bh[kk]), acc[K0 + kk], 0, 0, 0); \
+            }                                                                                                        \
+            acc[K0 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah),                    \
+                                                                   __builtin_bit_cast(bf16x8, bh[kk]), acc[K0 + kk], 0, 0, 0); \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+            WGRAD_GROUP(0, 3)
+            WGRAD_GROUP(3, 2)
+#undef WGRAD_GROUP
         }
     }
+#undef D_ROW
+#undef D_FR
+#undef D_V0
     // D[row = o][col = c]: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float *dst = part + (size_t)blockIdx.z * Cout * Cin * K;
 #pragma unroll
     for (int kk = 0; kk < KHMAX; ++kk) {
         const int k = k_lo + kk;
-        if (k < k_hi) {
+        if (kk < KH && k < K) {                   // (taps beyond this wave's group or beyond K were computed for nothing)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = o0 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -376,23 +418,25 @@ __global__ void sum_partials_kernel(const float *__restrict__ part, float *__res
 
 struct WgradPlan {
     bool ok = false;
-    int Vp = 0, tfm = 0, pitchA = 0, pitchB = 0, splits = 0;
+    int Vp = 0, tfm = 0, ub = 0, pitchA = 0, pitchB = 0, splits = 0;
     size_t lds = 0;
 };
 
 inline WgradPlan plan_wgrad(int N, int Cin, int Cout, int T, int V, int K, int stride) {
     WgradPlan pl;
     if (stride != 1 || K > 2 * KHMAX - 1 || K < 1 || Cout % 128 != 0 || Cin % 32 != 0) return pl;
+    if ((size_t)(Cin > Cout ? Cin : Cout) * T * V * 4 >= ((size_t)1 << 31)) return pl;   // per-clip buffer resources
     const int Vp = (V + 7) / 8 * 8;
     const int upf = Vp / 8;
     int TFM = 0;
     for (int t = TFM_MAX; t >= 1 && !TFM; t >>= 1)
-        if ((t * Vp) % 16 == 0 && 128 * t * upf <= 4 * WG_THREADS && 32 * (t + K - 1) * upf <= 4 * WG_THREADS) TFM = t;
+        if ((t * Vp) % 16 == 0 && 128 * t * upf <= 3 * WG_THREADS && 32 * (t + 2 * KHMAX - 1) * upf <= 5 * WG_THREADS) TFM = t;
     if (!TFM) return pl;
-    const int FRB = TFM + K - 1;
+    const int FRB = TFM + 2 * KHMAX - 1;          // the kernel stages taps 0 .. 2*KHMAX-1 whatever K is
     auto odd16 = [](int bytes) { int u = (bytes + 15) / 16; return (u | 1) * 16; };   // 16 B x odd: conflict-free rows
     pl.Vp = Vp;
     pl.tfm = TFM;
+    pl.ub = 32 * FRB * upf <= 3 * WG_THREADS ? 3 : 5;
     pl.pitchA = odd16(TFM * Vp * 2);
     pl.pitchB = odd16(FRB * Vp * 2);
     pl.lds = (size_t)2 * 128 * pl.pitchA + (size_t)2 * 32 * pl.pitchB;
@@ -495,15 +539,15 @@ int launch_tcn_wgrad(const float *dz, const float *x, float *dW, float *part, in
     const WgradPlan pl = plan_wgrad(N, Cin, Cout, T, V, K, stride);
     if ((math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) && pl.ok && part != nullptr) {
         const dim3 grid(Cin / 32, Cout / 128, pl.splits);
-        if (math == STGCN_MATH_BF16X3) {
-            STGCN_HIP_CHECK(allow_lds(tcn_wgrad_mfma_kernel<3>, pl.lds));
-            hipLaunchKernelGGL(tcn_wgrad_mfma_kernel<3>, grid, dim3(WG_THREADS), pl.lds, st, dz, x, part, N, Cin, Cout, T, V, K,
-                               pl.Vp, pl.pitchA, pl.pitchB, pl.tfm);
-        } else {
-            STGCN_HIP_CHECK(allow_lds(tcn_wgrad_mfma_kernel<1>, pl.lds));
-            hipLaunchKernelGGL(tcn_wgrad_mfma_kernel<1>, grid, dim3(WG_THREADS), pl.lds, st, dz, x, part, N, Cin, Cout, T, V, K,
-                               pl.Vp, pl.pitchA, pl.pitchB, pl.tfm);
-        }
+#define LAUNCH_WGRAD(TERMS, UBN)                                                                                       \
+    do {                                                                                                               \
+        STGCN_HIP_CHECK(allow_lds((tcn_wgrad_mfma_kernel<TERMS, UBN>), pl.lds));                                       \
+        hipLaunchKernelGGL((tcn_wgrad_mfma_kernel<TERMS, UBN>), grid, dim3(WG_THREADS), pl.lds, st, dz, x, part, N, Cin, Cout, \
+                           T, V, K, pl.Vp, pl.pitchA, pl.pitchB, pl.tfm);                                              \
+    } while (0)
+        if (math == STGCN_MATH_BF16X3) { if (pl.ub == 3) LAUNCH_WGRAD(3, 3); else LAUNCH_WGRAD(3, 5); }
+        else { if (pl.ub == 3) LAUNCH_WGRAD(1, 3); else LAUNCH_WGRAD(1, 5); }
+#undef LAUNCH_WGRAD
         STGCN_LAUNCH_CHECK("tcn_wgrad_mfma_kernel");
         const size_t n = (size_t)Cout * Cin * K;
         hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, dW, pl.splits, n);

@@ -641,3 +641,51 @@ def test_stem_training_step_vs_oracle(math, dev):
     ref.pop("t_b")
     _compare_grads(got, ref, 2e-3)
     parity_gate(tcn.bn.running_mean, aux["bn"]["running_mean"], 1e-4, "tcn running_mean")
+
+
+def _check_grads_vs_golden(mods, g, rel, extra=None):
+    """Module .grad tensors against the reference's own gradients (tests/golden/make_golden_bwd.py)."""
+    got = dict(extra or {})
+    for prefix, mod in mods.items():
+        for k, p in mod.named_parameters():
+            assert p.grad is not None, f"{prefix}{k}: no gradient"
+            got[prefix + k] = p.grad
+    bad = []
+    for name, val in got.items():
+        ref = torch.from_numpy(g["grad." + name]).double()
+        val = val.double().cpu().reshape(ref.shape)
+        scale = ref.abs().max().item()
+        if name.endswith(".bias") and any(t in name for t in ("conv_a", "conv_d", "down.0", "tcn.conv")):
+            scale = max(scale, float(np.abs(g["grad." + name.replace(".bias", ".weight")]).max()))   # structurally zero
+        err = (val - ref).abs().max().item()
+        if not (err <= rel * scale):
+            bad.append(f"{name}: {err:.3e} > {rel:g}*{scale:.3e}")
+    assert not bad, "; ".join(bad)
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "f32_valu"])
+def test_stem_backward_vs_reference_gradients(math, dev):
+    """loss.backward() through the drop-in modules against the gradients the REFERENCE's modules produced for the same
+    parameters, input and cotangent (fixture bwd_stem_shre_T20)."""
+    from stgcn_amd import set_math_mode
+    g = load_golden("bwd_stem_shre_T20")
+    gcn = build_gcn(g, 3, 128, dev).train()
+    tcn = build_tcn(g, 128, 128, 9, 1, True, dev).train()
+    set_math_mode(tcn, math)
+    z = tcn(gcn(torch.from_numpy(g["x"]).to(dev)))
+    parity_gate(z.detach(), g["z"], 1e-4, "train-mode stem forward")
+    z.backward(torch.from_numpy(g["G"]).to(dev))
+    _check_grads_vs_golden({"gcn.": gcn, "tcn.": tcn}, g, 1e-3)     # (inner ReLU kinks, see test_stem_training_step_vs_oracle)
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "f32_valu"])
+def test_strided_unit2d_backward_vs_reference_gradients(math, dev):
+    from stgcn_amd import set_math_mode
+    g = load_golden("bwd_tcn_64_128_k9_s2")
+    tcn = build_tcn(g, 64, 128, 9, 2, True, dev).train()
+    set_math_mode(tcn, math)
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+    z = tcn(x)
+    parity_gate(z.detach(), g["z"], 1e-4, "train-mode strided forward")
+    z.backward(torch.from_numpy(g["G"]).to(dev))
+    _check_grads_vs_golden({"tcn.": tcn}, g, 1e-4, extra={"x": x.grad})

@@ -120,3 +120,69 @@ def test_float64_oracle_close_to_float32_reference():
     p = so.tcn_params_from_state(sub_state(g, "tcn.")).to(torch.float64)
     y = so.tcn_forward(torch.from_numpy(g["x"]).double(), p)
     parity_gate(y, g["y_eval"], TIGHT, "fp64 oracle vs fp32 reference")
+
+
+# ---- backward: autograd through the oracle against gradient fixtures generated from the reference -----------------
+def _oracle_leaf_names(gp=None, tp=None):
+    """oracle leaf tensors keyed by the reference's parameter names (state_dict keys)."""
+    m = {}
+    if gp is not None:
+        m.update({"gcn.PA": gp.PA, "gcn.down.0.weight": gp.down_w, "gcn.down.0.bias": gp.down_b,
+                  "gcn.down.1.weight": gp.down_bn.weight, "gcn.down.1.bias": gp.down_bn.bias,
+                  "gcn.bn.weight": gp.bn.weight, "gcn.bn.bias": gp.bn.bias})
+        for i in range(gp.num_subset):
+            m.update({f"gcn.conv_a.{i}.weight": gp.conv_a_w[i], f"gcn.conv_a.{i}.bias": gp.conv_a_b[i],
+                      f"gcn.conv_b.{i}.weight": gp.conv_b_w[i], f"gcn.conv_b.{i}.bias": gp.conv_b_b[i],
+                      f"gcn.conv_d.{i}.weight": gp.conv_d_w[i], f"gcn.conv_d.{i}.bias": gp.conv_d_b[i]})
+    if tp is not None:
+        m.update({"tcn.conv.weight": tp.conv_w, "tcn.conv.bias": tp.conv_b, "tcn.bn.weight": tp.bn.weight,
+                  "tcn.bn.bias": tp.bn.bias})
+    return m
+
+
+def _zero_by_structure(name):
+    """Gradients that are exactly zero in exact arithmetic: biases in front of a batch-statistics BatchNorm and
+    conv_a's bias (constant shift of a soft-maxed column); held against their weight's gradient scale."""
+    return name.endswith(".bias") and any(t in name for t in ("conv_a", "conv_d", "down.0", "tcn.conv"))
+
+
+def _check_grads(got, g, rel):
+    bad = []
+    for name, val in got.items():
+        ref = torch.from_numpy(g["grad." + name]).double().reshape(val.shape)
+        scale = ref.abs().max().item()
+        if _zero_by_structure(name):
+            scale = max(scale, float(np.abs(g["grad." + name.replace(".bias", ".weight")]).max()))
+        err = (val.double() - ref).abs().max().item()
+        if err > rel * scale:
+            bad.append(f"{name}: {err:.3e} > {rel:g}*{scale:.3e}")
+    assert not bad, "; ".join(bad)
+
+
+def test_oracle_autograd_vs_reference_stem_gradients():
+    g = load_golden("bwd_stem_shre_T20")
+    gp = so.agcn_params_from_state(sub_state(g, "gcn."), torch.from_numpy(g["A_fixed"])).to(torch.float64)
+    tp = so.tcn_params_from_state(sub_state(g, "tcn.")).to(torch.float64)
+    leaves = _oracle_leaf_names(gp, tp)
+    for t in leaves.values():
+        t.requires_grad_(True)
+    z = so.stem_forward(torch.from_numpy(g["x"]).double(), gp, tp, training=True)
+    parity_gate(z.detach(), g["z"], 2e-5, "train-mode stem forward")
+    names = sorted(leaves)
+    grads = torch.autograd.grad((z * torch.from_numpy(g["G"]).double()).sum(), [leaves[k] for k in names])
+    _check_grads(dict(zip(names, grads)), g, 1e-3)     # (inner ReLU kinks: fp32 reference vs fp64 oracle)
+
+
+def test_oracle_autograd_vs_reference_strided_tcn_gradients():
+    g = load_golden("bwd_tcn_64_128_k9_s2")
+    tp = so.tcn_params_from_state(sub_state(g, "tcn."), stride=2).to(torch.float64)
+    leaves = _oracle_leaf_names(None, tp)
+    x = torch.from_numpy(g["x"]).double().requires_grad_(True)
+    leaves["x"] = x
+    for t in leaves.values():
+        t.requires_grad_(True)
+    z = so.tcn_forward(x, tp, training=True)
+    parity_gate(z.detach(), g["z"], 2e-5, "train-mode strided tcn forward")
+    names = sorted(leaves)
+    grads = torch.autograd.grad((z * torch.from_numpy(g["G"]).double()).sum(), [leaves[k] for k in names])
+    _check_grads(dict(zip(names, grads)), g, 1e-4)

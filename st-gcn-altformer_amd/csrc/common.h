@@ -65,6 +65,28 @@ static inline hipError_t allow_lds(K kernel, size_t bytes) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// Iteration shared by the elementwise kernels: workgroup (blockIdx.x, c = blockIdx.y) owns clips
+// [n_lo, n_hi) of channel c; a clip's plane of the channel is contiguous, so there is no division in the loop and,
+// when the plane is a multiple of 4 floats, every access is a 16-byte one.
+struct ChannelRows {
+    int n_lo, n_hi;
+    bool vec;
+    __device__ ChannelRows(int N, size_t plane) {
+        const int per = (N + (int)gridDim.x - 1) / (int)gridDim.x;
+        n_lo = blockIdx.x * per;
+        n_hi = min(N, n_lo + per);
+        vec = (plane & 3) == 0;
+    }
+};
+
+// grid.x of those kernels: ~64 K elements per workgroup and channel, at most one workgroup per clip
+static inline int bn_chunks(int N, size_t plane) {
+    int chunks = (int)(((size_t)N * plane + 65535) / 65536);
+    if (chunks > N) chunks = N;
+    if (chunks > 64) chunks = 64;
+    return chunks < 1 ? 1 : chunks;
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers implemented in the kernel translation units (all enqueue on `st`, return status)
 // ---------------------------------------------------------------------------------------

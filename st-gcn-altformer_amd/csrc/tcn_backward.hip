@@ -28,12 +28,6 @@ struct BnSide {
     const float *z, *scale, *shift, *mean, *invstd;
 };
 
-__device__ __forceinline__ float preact(const BnSide &a, const BnSide &b, size_t e, int c) {
-    float v = fmaf(a.z[e], a.scale[c], a.shift[c]);
-    if (b.z != nullptr) v += (b.scale != nullptr) ? fmaf(b.z[e], b.scale[c], b.shift[c]) : b.z[e];
-    return v;
-}
-
 __device__ __forceinline__ void block_sum3(double &s0, double &s1, double &s2, double (&red)[3][4]) {
     for (int o = 32; o > 0; o >>= 1) {
         s0 += __shfl_down(s0, o, 64);
@@ -48,24 +42,53 @@ __device__ __forceinline__ void block_sum3(double &s0, double &s1, double &s2, d
     s2 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
 }
 
+// Per-channel constants of one workgroup: pre-activation, ReLU mask and xhat of an element from its raw values.
+struct ChanCoef {
+    float sa, ta, ma, ia, sb, tb, mb, ib;
+    int mode;                                     // side b: 0 none, 1 identity residual, 2 second BatchNorm
+    __device__ ChanCoef(const BnSide &a, const BnSide &b, int c) {
+        sa = a.scale[c]; ta = a.shift[c]; ma = a.mean[c]; ia = a.invstd[c];
+        mode = b.z == nullptr ? 0 : (b.scale != nullptr ? 2 : 1);
+        sb = mode == 2 ? b.scale[c] : 1.f; tb = mode == 2 ? b.shift[c] : 0.f;
+        mb = mode == 2 ? b.mean[c] : 0.f; ib = mode == 2 ? b.invstd[c] : 0.f;
+    }
+    __device__ __forceinline__ float masked(float za, float zb, float dy) const {   // the forward's own expression
+        float v = fmaf(za, sa, ta);
+        if (mode) v += fmaf(zb, sb, tb);
+        return v > 0.f ? dy : 0.f;
+    }
+};
+
 // grid = (chunks, C)
 __global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(BnSide a, BnSide b, const float *__restrict__ dy,
                                                                  double *__restrict__ sums, int N, int C, size_t plane) {
     const int c = blockIdx.y;
-    const size_t per_chunk = (N * plane + gridDim.x - 1) / gridDim.x;
-    const size_t lo = blockIdx.x * per_chunk;
-    const size_t hi = min(lo + per_chunk, (size_t)N * plane);
-    const bool two = b.z != nullptr && b.scale != nullptr;
-    const float ma = a.mean[c], ia = a.invstd[c];
-    const float mb = two ? b.mean[c] : 0.f, ib = two ? b.invstd[c] : 0.f;
+    const ChannelRows it(N, plane);
+    const ChanCoef k(a, b, c);
+    const bool two = k.mode == 2;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (size_t q = lo + threadIdx.x; q < hi; q += 256) {
-        const size_t n = q / plane, p = q - n * plane;
-        const size_t e = (n * C + c) * plane + p;
-        const float g = preact(a, b, e, c) > 0.f ? dy[e] : 0.f;
-        s0 += (double)g;
-        s1 += (double)(g * ((a.z[e] - ma) * ia));
-        if (two) s2 += (double)(g * ((b.z[e] - mb) * ib));
+    for (int n = it.n_lo; n < it.n_hi; ++n) {
+        const size_t base = ((size_t)n * C + c) * plane;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;        // fp32 within one strip, fp64 across
+        auto one = [&](float za, float zb, float d) {
+            const float g = k.masked(za, zb, d);
+            a0 += g;
+            a1 = fmaf(g, (za - k.ma) * k.ia, a1);
+            if (two) a2 = fmaf(g, (zb - k.mb) * k.ib, a2);
+        };
+        if (it.vec) {
+            for (size_t p = threadIdx.x * 4; p < plane; p += 1024) {
+                const float4 va = *reinterpret_cast<const float4 *>(a.z + base + p);
+                const float4 vb = k.mode ? *reinterpret_cast<const float4 *>(b.z + base + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 vd = *reinterpret_cast<const float4 *>(dy + base + p);
+                one(va.x, vb.x, vd.x); one(va.y, vb.y, vd.y); one(va.z, vb.z, vd.z); one(va.w, vb.w, vd.w);
+            }
+        } else {
+            for (size_t p = threadIdx.x; p < plane; p += 256) one(a.z[base + p], k.mode ? b.z[base + p] : 0.f, dy[base + p]);
+        }
+        s0 += (double)a0;
+        s1 += (double)a1;
+        s2 += (double)a2;
     }
     __shared__ double red[3][4];
     block_sum3(s0, s1, s2, red);
@@ -100,26 +123,45 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(BnSide a, BnSide
                                                                  float *__restrict__ dzb, double *__restrict__ bsum, int N,
                                                                  int C, size_t plane) {
     const int c = blockIdx.y;
-    const size_t per_chunk = (N * plane + gridDim.x - 1) / gridDim.x;
-    const size_t lo = blockIdx.x * per_chunk;
-    const size_t hi = min(lo + per_chunk, (size_t)N * plane);
+    const ChannelRows it(N, plane);
+    const ChanCoef k(a, b, c);
     const bool two = dzb != nullptr;
-    const float ma = a.mean[c], ia = a.invstd[c], ka = coefa[c], c1 = coefa[C + c], c2a = coefa[2 * C + c];
-    const float mb = two ? b.mean[c] : 0.f, ib = two ? b.invstd[c] : 0.f, kb = two ? coefb[c] : 0.f,
-                c2b = two ? coefb[2 * C + c] : 0.f;
+    const float ka = coefa[c], c1 = coefa[C + c], c2a = coefa[2 * C + c];
+    const float kb = two ? coefb[c] : 0.f, c2b = two ? coefb[2 * C + c] : 0.f;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (size_t q = lo + threadIdx.x; q < hi; q += 256) {
-        const size_t n = q / plane, p = q - n * plane;
-        const size_t e = (n * C + c) * plane + p;
-        const float g = preact(a, b, e, c) > 0.f ? dy[e] : 0.f;
-        const float da = ka * (g - c1 - (a.z[e] - ma) * ia * c2a);
-        dza[e] = da;
-        s0 += (double)da;
-        if (two) {
-            const float db = kb * (g - c1 - (b.z[e] - mb) * ib * c2b);
-            dzb[e] = db;
-            s1 += (double)db;
+    for (int n = it.n_lo; n < it.n_hi; ++n) {
+        const size_t base = ((size_t)n * C + c) * plane;
+        float a0 = 0.f, a1 = 0.f;
+        auto one = [&](float za, float zb, float d, float &oa, float &ob) {
+            const float g = k.masked(za, zb, d);
+            oa = ka * (g - c1 - (za - k.ma) * k.ia * c2a);
+            a0 += oa;
+            if (two) {
+                ob = kb * (g - c1 - (zb - k.mb) * k.ib * c2b);
+                a1 += ob;
+            }
+        };
+        if (it.vec) {
+            for (size_t p = threadIdx.x * 4; p < plane; p += 1024) {
+                const float4 va = *reinterpret_cast<const float4 *>(a.z + base + p);
+                const float4 vb = k.mode ? *reinterpret_cast<const float4 *>(b.z + base + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 vd = *reinterpret_cast<const float4 *>(dy + base + p);
+                float4 oa, ob = make_float4(0.f, 0.f, 0.f, 0.f);
+                one(va.x, vb.x, vd.x, oa.x, ob.x); one(va.y, vb.y, vd.y, oa.y, ob.y);
+                one(va.z, vb.z, vd.z, oa.z, ob.z); one(va.w, vb.w, vd.w, oa.w, ob.w);
+                *reinterpret_cast<float4 *>(dza + base + p) = oa;
+                if (two) *reinterpret_cast<float4 *>(dzb + base + p) = ob;
+            }
+        } else {
+            for (size_t p = threadIdx.x; p < plane; p += 256) {
+                float oa, ob = 0.f;
+                one(a.z[base + p], k.mode ? b.z[base + p] : 0.f, dy[base + p], oa, ob);
+                dza[base + p] = oa;
+                if (two) dzb[base + p] = ob;
+            }
         }
+        s0 += (double)a0;
+        s1 += (double)a1;
     }
     if (bsum == nullptr) return;
     __shared__ double red[3][4];
@@ -456,19 +498,13 @@ inline WgradPlan plan_wgrad(int N, int Cin, int Cout, int T, int V, int K, int s
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
-static int chunks_for(size_t per_channel) {
-    int chunks = (int)((per_channel + 16383) / 16384);
-    if (chunks > 64) chunks = 64;
-    return chunks < 1 ? 1 : chunks;
-}
-
 // sums: 3*C doubles (zeroed here).  Side b: z == NULL (none), scale == NULL (identity residual), else second BatchNorm.
 int launch_bn_relu_bwd_stats(const float *za, const float *sa, const float *ta, const float *ma, const float *ia,
                              const float *zb, const float *sb, const float *tb, const float *mb, const float *ib,
                              const float *dy, double *sums, int N, int C, size_t plane, hipStream_t st) {
     STGCN_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 3 * C, st));
     const BnSide a{za, sa, ta, ma, ia}, b{zb, sb, tb, mb, ib};
-    hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(chunks_for((size_t)N * plane), C), dim3(256), 0, st, a, b, dy, sums, N,
+    hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(bn_chunks(N, plane), C), dim3(256), 0, st, a, b, dy, sums, N,
                        C, plane);
     STGCN_LAUNCH_CHECK("bn_relu_bwd_stats_kernel");
     return STGCN_OK;
@@ -489,7 +525,7 @@ int launch_bn_relu_bwd_apply(const float *za, const float *sa, const float *ta, 
                              int N, int C, size_t plane, hipStream_t st) {
     if (bsum) STGCN_HIP_CHECK(hipMemsetAsync(bsum, 0, sizeof(double) * 2 * C, st));
     const BnSide a{za, sa, ta, ma, ia}, b{zb, sb, tb, mb, ib};
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(chunks_for((size_t)N * plane), C), dim3(256), 0, st, a, b, dy, coefa,
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(bn_chunks(N, plane), C), dim3(256), 0, st, a, b, dy, coefa,
                        coefb, dza, dzb, bsum, N, C, plane);
     STGCN_LAUNCH_CHECK("bn_relu_bwd_apply_kernel");
     return STGCN_OK;

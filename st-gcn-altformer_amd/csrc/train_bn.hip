@@ -15,15 +15,26 @@ namespace {
 __global__ __launch_bounds__(256) void bn_batch_stats_kernel(const float *__restrict__ z, double *__restrict__ sums,
                                                               int N, int C, size_t plane) {
     const int c = blockIdx.y;
-    const size_t per_chunk = (N * plane + gridDim.x - 1) / gridDim.x;
-    const size_t lo = blockIdx.x * per_chunk;
-    const size_t hi = min(lo + per_chunk, (size_t)N * plane);
+    const ChannelRows it(N, plane);
     double s1 = 0.0, s2 = 0.0;
-    for (size_t e = lo + threadIdx.x; e < hi; e += 256) {
-        const size_t n = e / plane, p = e - n * plane;
-        const double v = (double)z[(n * C + c) * plane + p];
-        s1 += v;
-        s2 += v * v;
+    for (int n = it.n_lo; n < it.n_hi; ++n) {
+        const float *zr = z + ((size_t)n * C + c) * plane;
+        float a1 = 0.f, a2 = 0.f;                  // fp32 within one (clip, channel, thread) strip, fp64 across
+        if (it.vec) {
+            for (size_t p = threadIdx.x * 4; p < plane; p += 1024) {
+                const float4 v = *reinterpret_cast<const float4 *>(zr + p);
+                a1 += (v.x + v.y) + (v.z + v.w);
+                a2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, a2))));
+            }
+        } else {
+            for (size_t p = threadIdx.x; p < plane; p += 256) {
+                const float v = zr[p];
+                a1 += v;
+                a2 = fmaf(v, v, a2);
+            }
+        }
+        s1 += (double)a1;
+        s2 += (double)a2;
     }
     for (int o = 32; o > 0; o >>= 1) {
         s1 += __shfl_down(s1, o, 64);
@@ -63,15 +74,32 @@ __global__ void bn_train_finalize_kernel(const double *__restrict__ sums, double
 }
 
 // y = relu( za*sa[c] + ta[c] + r ),  r = zb*sb[c] + tb[c]  (sb given), = zb (sb NULL, identity residual), = 0 (zb NULL)
+// grid = (chunks, C)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ za, const float *__restrict__ sa,
                                                         const float *__restrict__ ta, const float *__restrict__ zb,
                                                         const float *__restrict__ sb, const float *__restrict__ tb,
-                                                        float *__restrict__ y, size_t total, int C, size_t plane) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int c = (int)((e / plane) % C);
-        float v = fmaf(za[e], sa[c], ta[c]);
-        if (zb != nullptr) v += (sb != nullptr) ? fmaf(zb[e], sb[c], tb[c]) : zb[e];
-        y[e] = fmaxf(v, 0.f);
+                                                        float *__restrict__ y, int N, int C, size_t plane) {
+    const int c = blockIdx.y;
+    const ChannelRows it(N, plane);
+    const float s_a = sa[c], t_a = ta[c];
+    const int mode = zb == nullptr ? 0 : (sb != nullptr ? 2 : 1);
+    const float s_b = mode == 2 ? sb[c] : 1.f, t_b = mode == 2 ? tb[c] : 0.f;
+    auto one = [&](float a, float b) {
+        float v = fmaf(a, s_a, t_a);
+        if (mode) v += fmaf(b, s_b, t_b);          // (mode 1: 1*b + 0, the same bits as v + b)
+        return fmaxf(v, 0.f);
+    };
+    for (int n = it.n_lo; n < it.n_hi; ++n) {
+        const size_t base = ((size_t)n * C + c) * plane;
+        if (it.vec) {
+            for (size_t p = threadIdx.x * 4; p < plane; p += 1024) {
+                const float4 a = *reinterpret_cast<const float4 *>(za + base + p);
+                const float4 b = mode ? *reinterpret_cast<const float4 *>(zb + base + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(y + base + p) = make_float4(one(a.x, b.x), one(a.y, b.y), one(a.z, b.z), one(a.w, b.w));
+            }
+        } else {
+            for (size_t p = threadIdx.x; p < plane; p += 256) y[base + p] = one(za[base + p], mode ? zb[base + p] : 0.f);
+        }
     }
 }
 
@@ -98,11 +126,7 @@ int launch_bn_scale_shift(const float *weight, const float *bias, const float *m
 
 int launch_bn_batch_stats(const float *z, double *sums, int N, int C, size_t plane, hipStream_t st) {
     STGCN_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
-    const size_t per_c = (size_t)N * plane;
-    int chunks = (int)((per_c + 16383) / 16384);
-    if (chunks > 64) chunks = 64;
-    if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(bn_batch_stats_kernel, dim3(chunks, C), dim3(256), 0, st, z, sums, N, C, plane);
+    hipLaunchKernelGGL(bn_batch_stats_kernel, dim3(bn_chunks(N, plane), C), dim3(256), 0, st, z, sums, N, C, plane);
     STGCN_LAUNCH_CHECK("bn_batch_stats_kernel");
     return STGCN_OK;
 }
@@ -118,10 +142,8 @@ int launch_bn_train_finalize(const double *sums, double count, const float *weig
 
 int launch_bn_apply(const float *za, const float *sa, const float *ta, const float *zb, const float *sb,
                     const float *tb, float *y, size_t total, int C, size_t plane, hipStream_t st) {
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, za, sa, ta, zb, sb, tb, y, total, C,
-                       plane);
+    const int N = (int)(total / ((size_t)C * plane));
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_chunks(N, plane), C), dim3(256), 0, st, za, sa, ta, zb, sb, tb, y, N, C, plane);
     STGCN_LAUNCH_CHECK("bn_apply_kernel");
     return STGCN_OK;
 }

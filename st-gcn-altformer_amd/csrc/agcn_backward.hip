@@ -19,6 +19,8 @@ namespace stgcn {
 namespace {
 
 constexpr int PXMAX = 256;   // pixels per frame chunk
+constexpr int FP = 260;      // row pitch of the x / feature / du tiles: rows 4 banks apart (a pitch of 256 floats put all
+                             // 16 feature rows of phase (b) on the same banks: 2/3 of the LDS cycles were conflicts)
 constexpr int DP = 260;      // row pitch of the dz tiles: 16-byte aligned rows, 8 consecutive rows on distinct banks
 constexpr int NTB = 512;     // threads per workgroup
 constexpr int NCST = 12;     // per-channel constants (10 used)
@@ -41,10 +43,10 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
     const int VV = V * V;
     float *Dm = sm;                                  // [32][DP] dzm of the channel block   (16-byte aligned rows)
     float *Dd = Dm + 32 * DP;                        // [32][DP] dzd
-    float *Xs = Dd + 32 * DP;                        // [CIN][PXMAX]
-    float *Fs = Xs + CIN * PXMAX;                    // [SC][PXMAX] u_s
-    float *DUs = Fs + SC * PXMAX;                    // [SC][PXMAX] du_s
-    float *cst = DUs + SC * PXMAX;                   // [Cout][NCST] per-channel constants of the two BatchNorm backward maps
+    float *Xs = Dd + 32 * DP;                        // [CIN][FP]
+    float *Fs = Xs + CIN * FP;                       // [SC][FP] u_s
+    float *DUs = Fs + SC * FP;                       // [SC][FP] du_s
+    float *cst = DUs + SC * FP;                   // [Cout][NCST] per-channel constants of the two BatchNorm backward maps
     float *red = cst + Cout * NCST;                  // [8][S*C1*C1] block reduction of dM
     float *Ps = red + 8 * S * C1 * C1;               // [S][V][V]  P of the clip
     float *dPs = Ps + S * VV;                        // [S][V][V]  dP, later dS
@@ -84,9 +86,9 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
             __syncthreads();
             for (int e = tid; e < CIN * px; e += NTB) {
                 const int k = e / px, p = e - k * px;
-                Xs[k * PXMAX + p] = xn[(size_t)k * plane + (size_t)t0 * V + p];
+                Xs[k * FP + p] = xn[(size_t)k * plane + (size_t)t0 * V + p];
             }
-            for (int e = tid; e < SC * PXMAX; e += NTB) DUs[e] = 0.f;
+            for (int e = tid; e < SC * FP; e += NTB) DUs[e] = 0.f;
             __syncthreads();
             if (tid < px) {                          // u_s[k] of this thread's pixel (model/unit_agcn.py:87-88)
                 const int tt = tid / V, w = tid - tt * V;
@@ -98,11 +100,11 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
                     for (int s = 0; s < S; ++s) {
                         const float pw = Ps[(s * V + v) * V + w];
 #pragma unroll
-                        for (int k = 0; k < CIN; ++k) u[s * CIN + k] = fmaf(Xs[k * PXMAX + tt * V + v], pw, u[s * CIN + k]);
+                        for (int k = 0; k < CIN; ++k) u[s * CIN + k] = fmaf(Xs[k * FP + tt * V + v], pw, u[s * CIN + k]);
                     }
                 }
 #pragma unroll
-                for (int f = 0; f < SC; ++f) Fs[f * PXMAX + tid] = u[f];
+                for (int f = 0; f < SC; ++f) Fs[f * FP + tid] = u[f];
             }
             float du[SC];
 #pragma unroll
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
                     const bool main_side = col <= SC;
                     const float *dr = (main_side ? Dm : Dd) + ol * DP;
                     const bool is_bias = col == SC || col == WCOLS - 1;
-                    const float *fr = col < SC ? Fs + col * PXMAX : Xs + (is_bias ? 0 : col - SC - 1) * PXMAX;
+                    const float *fr = col < SC ? Fs + col * FP : Xs + (is_bias ? 0 : col - SC - 1) * FP;
                     float a = 0.f;
                     const int px4 = px & ~3;
                     if (is_bias) {
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
             }
             if (pa < px) {                           // the two halves' du (a + b: order-independent)
 #pragma unroll
-                for (int f = 0; f < SC; ++f) atomicAdd(&DUs[f * PXMAX + pa], du[f]);
+                for (int f = 0; f < SC; ++f) atomicAdd(&DUs[f * FP + pa], du[f]);
             }
             __syncthreads();
             const int tf = px / V;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
                 for (int tt = 0; tt < tf; ++tt)
 #pragma unroll
                     for (int k = 0; k < CIN; ++k)
-                        a = fmaf(Xs[k * PXMAX + tt * V + v], DUs[(s * CIN + k) * PXMAX + tt * V + w], a);
+                        a = fmaf(Xs[k * FP + tt * V + v], DUs[(s * CIN + k) * FP + tt * V + w], a);
                 dPs[e] += a;
             }
         }
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
             __syncthreads();
             for (int e = tid; e < CIN * px; e += NTB) {
                 const int k = e / px, p = e - k * px;
-                Xs[k * PXMAX + p] = xn[(size_t)k * plane + (size_t)t0 * V + p];
+                Xs[k * FP + p] = xn[(size_t)k * plane + (size_t)t0 * V + p];
             }
             __syncthreads();
             for (int it = tid; it < S * px; it += NTB) {
@@ -233,12 +235,12 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
                 for (int w = 0; w < V; ++w) {
                     const float dsv = ds[w];
 #pragma unroll
-                    for (int l = 0; l < CIN; ++l) r[l] = fmaf(dsv, Xs[l * PXMAX + tt * V + w], r[l]);
+                    for (int l = 0; l < CIN; ++l) r[l] = fmaf(dsv, Xs[l * FP + tt * V + w], r[l]);
                     r[CIN] += dsv;
                 }
                 float xt[C1];
 #pragma unroll
-                for (int k = 0; k < CIN; ++k) xt[k] = Xs[k * PXMAX + p];
+                for (int k = 0; k < CIN; ++k) xt[k] = Xs[k * FP + p];
                 xt[CIN] = 1.f;
 #pragma unroll
                 for (int s2 = 0; s2 < S; ++s2)
@@ -343,7 +345,7 @@ inline AgcnBwdPlan plan_agcn_bwd(int N, int Cin, int Cout, int T, int V, int S) 
     const int SC = S * Cin, C1 = Cin + 1;
     int TF = PXMAX / V;
     if (TF > T) TF = T;
-    const size_t fl = (size_t)2 * 32 * DP + (size_t)(Cin + 2 * SC) * PXMAX + (size_t)Cout * NCST + (size_t)8 * S * C1 * C1 +
+    const size_t fl = (size_t)2 * 32 * DP + (size_t)(Cin + 2 * SC) * FP + (size_t)Cout * NCST + (size_t)8 * S * C1 * C1 +
                       (size_t)2 * S * V * V;
     pl.lds = fl * 4;
     if (pl.lds > (size_t)kLdsBytes) return pl;

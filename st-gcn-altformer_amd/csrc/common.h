@@ -126,6 +126,11 @@ bool stem_v4_supported(int Cin, int C, int T, int V, int K, int S, unsigned flag
 int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, const float *shift, void *out, int N,
                    int C, int T, int V, int K, unsigned flags, hipStream_t st);  // honours STGCN_OUT_NTVC
 
+// stand-alone temporal conv in the large-tile persistent form (stem_bf16_v4.hip): K = 9, stride 1, Cout % 128 == 0
+bool tcn_v4_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
+int launch_tcn_v4(const float *x, const void *Wp, const float *shift, void *y, int N, int Cin, int Cout, int T, int V, int K,
+                  int stride, unsigned flags, hipStream_t st);
+
 // training-mode BatchNorm helpers (train_bn.hip)
 int launch_bn_batch_stats(const float *z, double *sums, int N, int C, size_t plane, hipStream_t st);
 int launch_bn_train_finalize(const double *sums, double count, const float *weight, const float *bias,

@@ -388,6 +388,232 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
 #endif
 }
 
+// =====================================================================================================
+// K3v4 — the stand-alone temporal conv block (Unit2D: K = 9, stride 1) in the same large-tile persistent form:
+// same tile, weight ring, fenced tap body and epilogue as KF4; the matrix-core producer is replaced by staging of the
+// real fp32 input.  A thread owns two (pixel, 8-channel) units of the chunk image: 8 coalesced dword loads each
+// (lanes run along the pixels of one channel), issued at tap 0 for the NEXT chunk, split into bf16 hi/lo and stored
+// as one 16-byte LDS store per image at taps 6 and 7.  Chunk 0 of the next tile is loaded during the last chunk and
+// kept in registers across the epilogue (the image buffers are the epilogue's staging area).
+// Serves the training path (raw forward conv, and the input gradient = this kernel on flipped weights) and Unit2D.eval.
+// =====================================================================================================
+template <int TERMS, bool BF16OUT>
+__global__ __launch_bounds__(NT4) void tcn_bf16_v4_kernel(
+    const float *__restrict__ x, const uint4 *__restrict__ Wp, const float *__restrict__ shift, void *y, int Cin, int C,
+    int T, int V, int ROWS, int tiles_per_clip, int ntiles, float act_lo, int abl) {
+    extern __shared__ __attribute__((aligned(16))) char smem4[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int TV = T * V;
+    const int nch = Cin / CCB;
+    const int nstage = nch * (KT4 / STG);
+    const int img_bytes = ROWS * PXB;
+    const int buf_bytes = img_bytes * (TERMS == 3 ? 2 : 1);
+    char *ring = smem4;                                             // 2 stages x 3 taps x 8 fragments
+    char *buf0 = ring + 2 * STAGE_BYTES;                            // images; also the epilogue staging (8 x EPI_BYTES)
+    char *buf1 = buf0 + buf_bytes;
+    const unsigned ring_lds = (unsigned)(size_t)(lptr_t)smem4;
+    const int cg = blockIdx.y;
+    const uint4 *wsrc = Wp + ((size_t)(cg * 4 + (wave >> 1)) * nch * KT4 * 2 + (wave & 1)) * 64 + lane;
+    auto dma_stage = [&](int gs) {
+        const unsigned dst = ring_lds + (gs & 1) * STAGE_BYTES + wave * FRAG;
+        const int gsm = gs % nstage;
+#pragma unroll
+        for (int t = 0; t < STG; ++t) dma16(wsrc + (size_t)(gsm * STG + t) * 128, dst + t * 8 * FRAG);
+    };
+
+    // ---- input staging: units u = tid, tid + 512 of the chunk image; unit = (pixel row u % ROWS, channel half u / ROWS)
+    // (buffer-resource loads: one offset register per unit, the 8 channel strides ride in the scalar offset, and a
+    //  pixel outside the clip gets an offset past num_records, which reads as zero)
+    // (buffer-resource loads: one offset register per unit, the 8 channel strides ride in the scalar offset, and a
+    //  pixel outside the clip gets an offset past num_records, which reads as zero)
+    float pv[2][8];
+    auto load_units = [&](int n, const TileGeomB &g, int ch) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x + ((size_t)n * Cin + ch * CCB) * TV), 0, (unsigned)(CCB * TV * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = tid + i * NT4, hh = u >= ROWS ? 1 : 0, p = u - hh * ROWS;
+            const int gi = g.origin + p;
+            const bool ok = u < 2 * ROWS && p < g.span && gi >= 0 && gi < TV;
+            const unsigned off = ok ? (unsigned)((hh * 8 * TV + gi) * 4) : 0x7ffffff0u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                pv[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, c * TV * 4, 0));
+        }
+    };
+    auto store_unit = [&](char *buf, int i) {
+        const int u = tid + i * NT4, hh = u >= ROWS ? 1 : 0, p = u - hh * ROWS;
+        if (u < 2 * ROWS) {
+            uint4 hi, lo;
+            split8(pv[i], hi, lo);
+            const int off = lds_off(p, hh);
+            *reinterpret_cast<uint4 *>(buf + off) = hi;
+            if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(buf + img_bytes + off) = lo;
+        }
+    };
+
+    int tile = blockIdx.x;
+    dma_stage(0);
+    if (tile < ntiles) {
+        const int n = tile / tiles_per_clip;
+        load_units(n, tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NP4), 0);
+    }
+    dma_wait();                                   // (vmcnt(0): weight stage 0 and the first chunk's loads)
+    int gs = 0;
+    const int h = lane >> 5;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_clip;
+        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NP4);
+        const int next_tile = tile + gridDim.x;
+        TileGeomB g2 = g;
+        int n2 = n;
+        if (next_tile < ntiles) {
+            n2 = next_tile / tiles_per_clip;
+            g2 = tile_geom_b(next_tile - n2 * tiles_per_clip, V, KT4, 1, T, NP4);
+        }
+        store_unit(buf0, 0);                      // chunk 0 (loaded before the loop / during the previous tile's last chunk)
+        store_unit(buf0, 1);
+        int prow[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
+            q = min(q, g.q_last);
+            const int t = q / V, v = q - t * V;
+            prow[j] = (t - g.t_first) * V + v;
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+        __syncthreads();                          // chunk 0 and the current weight stage visible
+        auto load_a = [&](Frag2<TERMS> &a, const char *aslot, int tt) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                a.hi[m] = *reinterpret_cast<const uint4 *>(aslot + (tt * 8 + m * 2) * FRAG);
+                if constexpr (TERMS == 3) a.lo[m] = *reinterpret_cast<const uint4 *>(aslot + (tt * 8 + m * 2 + 1) * FRAG);
+            }
+        };
+        auto load_b = [&](Frag2<TERMS> &b, const char *img, int tap) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = lds_off(prow[j] + tap * V, h);
+                b.hi[j] = *reinterpret_cast<const uint4 *>(img + off);
+                if constexpr (TERMS == 3) b.lo[j] = *reinterpret_cast<const uint4 *>(img + img_bytes + off);
+            }
+        };
+        Frag2<TERMS> a_cur = {}, b_cur = {}, a_nxt = {}, b_nxt = {};
+        for (int ch = 0; ch < nch; ++ch) {
+            const char *cur = (ch & 1) ? buf1 : buf0;
+            char *nxt = (ch & 1) ? buf0 : buf1;
+            const bool last = ch + 1 == nch;
+            load_b(b_cur, cur, 0);
+#pragma unroll
+            for (int st = 0; st < KT4 / STG; ++st, ++gs) {
+                const char *aslot = ring + (gs & 1) * STAGE_BYTES + (wm * 4) * FRAG + lane * 16;
+                load_a(a_cur, aslot, 0);
+#pragma unroll
+                for (int tt = 0; tt < STG; ++tt) {
+                    const int tap = st * STG + tt;
+                    if (tt + 1 < STG) load_a(a_nxt, aslot, tt + 1);
+                    if (tap + 1 < KT4) load_b(b_nxt, cur, tap + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_half_bf16<TERMS>(acc, a_cur, b_cur, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tt == 0) dma_stage(gs + 1);
+                    if (tap == 0) {               // the next chunk's (or, in the last chunk, the next tile's first) input
+                        if (!last) load_units(n, g, ch + 1);
+                        else if (next_tile < ntiles) load_units(n2, g2, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_half_bf16<TERMS>(acc, a_cur, b_cur, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!last && tap == 6) store_unit(nxt, 0);
+                    if (!last && tap == 7) store_unit(nxt, 1);
+                    a_cur = a_nxt;
+                    b_cur = b_nxt;
+                }
+                dma_wait();
+                __syncthreads();                  // stage done: next weights landed and visible; chunk boundary at st == 2
+            }
+        }
+        // epilogue (see KF4): each 32-channel x 64-pixel block through this wave's 8 KiB staging slice, 16 B per lane
+        {
+            float *stg = reinterpret_cast<float *>(buf0 + wave * EPI_BYTES);
+            const int qw = g.q0 + wn * 64;
+            if (abl & OPT_OUT_NTVC) {
+                const int hh = lane >> 5;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int ob = cg * 128 + (wm * 2 + m) * 32;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 sh4 = *reinterpret_cast<const float4 *>(shift + ob + 8 * gq + 4 * hh);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int px = j * 32 + (lane & 31);
+                            const float4 v = make_float4(fmaxf(acc[m][j][4 * gq + 0] + sh4.x, act_lo), fmaxf(acc[m][j][4 * gq + 1] + sh4.y, act_lo),
+                                                         fmaxf(acc[m][j][4 * gq + 2] + sh4.z, act_lo), fmaxf(acc[m][j][4 * gq + 3] + sh4.w, act_lo));
+                            *reinterpret_cast<float4 *>(stg + px * 32 + (((2 * gq + hh) ^ (px & 7)) << 2)) = v;
+                        }
+                    }
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int idx = it * 64 + lane, px = idx >> 3, sl = idx & 7;
+                        const float4 v = *reinterpret_cast<const float4 *>(stg + px * 32 + ((sl ^ (px & 7)) << 2));
+                        const int q = qw + px;
+                        const size_t gidx = ((size_t)n * TV + q) * C + ob + 4 * sl;
+                        if (q <= g.q_last) {
+                            if constexpr (BF16OUT)
+                                *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + gidx) =
+                                    make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                            else
+                                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + gidx) = v;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int ob = cg * 128 + (wm * 2 + m) * 32;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const float sh = shift[ob + cr];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) stg[cr * 64 + j * 32 + (lane & 31)] = fmaxf(acc[m][j][r] + sh, act_lo);
+                    }
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int idx = it * 64 + lane, row = idx >> 4, c4 = (idx & 15) * 4;
+                        const float4 v = *reinterpret_cast<const float4 *>(stg + row * 64 + c4);
+                        const int q = qw + c4;
+                        const size_t gidx = ((size_t)n * C + ob + row) * TV + q;
+                        if (q + 3 <= g.q_last && (gidx & 3) == 0) {       // 16-byte (8-byte for bf16) aligned store
+                            if constexpr (BF16OUT)
+                                *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + gidx) =
+                                    make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                            else
+                                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + gidx) = v;
+                        } else {
+                            const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (q + e <= g.q_last) store_out<BF16OUT>(y, gidx + e, e4[e]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                          // staging consumed before the next tile's chunk 0 is stored
+    }
+}
+
 struct V4Plan {
     int pb = 0, rows = 0, tiles_per_clip = 0;
     size_t lds = 0;
@@ -433,7 +659,65 @@ int launch_v4(const float4 *feat, const float *W12, const uint4 *Wp, const float
     return STGCN_OK;
 }
 
+struct T4Plan {
+    int rows = 0, tiles_per_clip = 0;
+    size_t lds = 0;
+};
+
+inline bool plan_t4(int Cin, int Cout, int T, int V, int K, int stride, int terms, T4Plan &pl) {
+    if (K != KT4 || stride != 1 || Cout % 128 != 0 || Cin % CCB != 0 || T < 1) return false;
+    int dt = ceil_div(NP4 - 1, V);
+    if (dt > T - 1) dt = T - 1;
+    const int span = (dt + K) * V;
+    const int rows = (span + 7) / 8 * 8;
+    if (rows > NT4) return false;                 // two (pixel, 8-channel) units per thread
+    const size_t buf = (size_t)rows * PXB * (terms == 3 ? 2 : 1);
+    const size_t img = 2 * buf > (size_t)8 * EPI_BYTES ? 2 * buf : (size_t)8 * EPI_BYTES;
+    pl.lds = 2 * STAGE_BYTES + img;
+    if (pl.lds > (size_t)kLdsBytes) return false;
+    pl.rows = rows;
+    pl.tiles_per_clip = ceil_div(T * V, NP4);
+    return true;
+}
+
 }  // namespace
+
+bool tcn_v4_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags) {
+    const unsigned math = flags & STGCN_MATH_MASK;
+    if (math != STGCN_MATH_BF16X3 && math != STGCN_MATH_BF16) return false;
+    T4Plan pl;
+    return plan_t4(Cin, Cout, T, V, K, stride, math == STGCN_MATH_BF16X3 ? 3 : 1, pl);
+}
+
+int launch_tcn_v4(const float *x, const void *Wp, const float *shift, void *y, int N, int Cin, int Cout, int T, int V, int K,
+                  int stride, unsigned flags, hipStream_t st) {
+    const unsigned math = flags & STGCN_MATH_MASK;
+    const int terms = math == STGCN_MATH_BF16X3 ? 3 : 1;
+    const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
+    const float act_lo = (flags & STGCN_RAW) ? -__builtin_huge_valf() : 0.f;
+    const int opt = (flags & STGCN_OUT_NTVC) ? OPT_OUT_NTVC : 0;
+    T4Plan pl;
+    if (!plan_t4(Cin, Cout, T, V, K, stride, terms, pl))
+        return fail(STGCN_ERR_UNSUPPORTED, "tcn v4 kernel does not cover Cin=%d Cout=%d T=%d V=%d K=%d stride=%d", Cin, Cout, T,
+                    V, K, stride);
+    int dev = 0, num_cu = 256;
+    STGCN_HIP_CHECK(hipGetDevice(&dev));
+    STGCN_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int ntiles = N * pl.tiles_per_clip;
+    const dim3 grid(ntiles < num_cu ? ntiles : num_cu, Cout / 128, 1);
+#define LAUNCH_T4(TERMS, B)                                                                                       \
+    do {                                                                                                          \
+        auto kern = tcn_bf16_v4_kernel<TERMS, B>;                                                                 \
+        STGCN_HIP_CHECK(allow_lds(kern, pl.lds));                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, x, (const uint4 *)Wp, shift, y, Cin, Cout, T, V, pl.rows, \
+                           pl.tiles_per_clip, ntiles, act_lo, opt);                                               \
+    } while (0)
+    if (terms == 3) { if (bf16out) LAUNCH_T4(3, true); else LAUNCH_T4(3, false); }
+    else { if (bf16out) LAUNCH_T4(1, true); else LAUNCH_T4(1, false); }
+#undef LAUNCH_T4
+    STGCN_LAUNCH_CHECK("tcn_bf16_v4_kernel");
+    return STGCN_OK;
+}
 
 bool stem_v4_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags) {
     const unsigned math = flags & STGCN_MATH_MASK;

@@ -609,6 +609,7 @@ bool bf16_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned
         StemPlan sp;
         return Cin == Cout && stride == 1 && plan_stem_bf16(Cin, V, K, T, terms, sp);
     }
+    if (tcn_v4_supported(Cin, Cout, T, V, K, stride, flags)) return true;
     Bf16Plan pl;
     return plan_bf16(Cin, Cout, V, K, stride, Tout, terms, pl);
 }
@@ -640,6 +641,8 @@ int launch_tcn_bf16(const float *x, const float *P, const float *W12, const void
         if (terms == 3) return dispatch_stem<3>(x, P, W12, (const uint4 *)Wp, shift, y, N, Cin, T, V, K, sp, bf16out, opt, st);
         return dispatch_stem<1>(x, P, W12, (const uint4 *)Wp, shift, y, N, Cin, T, V, K, sp, bf16out, opt, st);
     }
+    if (tcn_v4_supported(Cin, Cout, T, V, K, stride, flags))   // K = 9, stride 1: large-tile persistent kernel
+        return launch_tcn_v4(x, Wp, shift, y, N, Cin, Cout, T, V, K, stride, flags, st);
     Bf16Plan pl;
     if (Tout < 1 || !plan_bf16(Cin, Cout, V, K, stride, Tout, terms, pl))
         return fail(STGCN_ERR_UNSUPPORTED,

@@ -23,7 +23,8 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+    newest = lambda paths: sorted(paths, key=os.path.getmtime)[-1:]   # gpurun_out/ accumulates earlier runs' files
+    stats = newest(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")))
     if stats:
         rows = list(csv.reader(open(stats[0])))
         head, body = rows[0], rows[1:]
@@ -34,7 +35,7 @@ def main():
             w.writerows(body[:12])
     counters = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-        for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+        for f in newest(glob.glob(os.path.join(d, "*", "*counter_collection.csv"))):
             for r in csv.DictReader(open(f)):
                 name = r["Kernel_Name"]
                 if "stgcn" not in name:

@@ -689,3 +689,73 @@ def test_strided_unit2d_backward_vs_reference_gradients(math, dev):
     parity_gate(z.detach(), g["z"], 1e-4, "train-mode strided forward")
     z.backward(torch.from_numpy(g["G"]).to(dev))
     _check_grads_vs_golden({"tcn.": tcn}, g, 1e-4, extra={"x": x.grad})
+
+
+@pytest.mark.parametrize("cin,cout,N,T,V,out_bf16", [
+    (128, 128, 40, 180, 22, False),    # 1240 tiles on 256 workgroups: every workgroup runs several tiles (input prefetch
+    (64, 128, 3, 5, 22, False),        #   across the tile boundary);  C_in != C_out, a single short tile
+    (128, 256, 6, 70, 25, True),       # odd T*V (unaligned rows), two 128-channel groups, bf16 output
+    (16, 128, 30, 200, 7, False),      # one channel chunk, narrow frames: many tiles per clip
+    (128, 128, 2, 1, 22, False)])      # T = 1
+def test_large_tile_temporal_conv_kernel(cin, cout, N, T, V, out_bf16, dev):
+    """K3v4 (stand-alone temporal conv, K = 9, stride 1, bf16x3) against the fp32 VALU kernel on the whole batch and
+    against the fp64 oracle on sampled clips; also in raw (pre-activation) mode, which the training forward uses."""
+    from stgcn_amd import Unit2D, functional as F, set_math_mode
+    from oracle import stgcn_oracle as so
+    gen = torch.Generator().manual_seed(cin + cout + T + V)
+    torch.manual_seed(7)
+    m = Unit2D(cin, cout, kernel_size=9)
+    with torch.no_grad():
+        m.conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
+        m.bn.weight.copy_(torch.rand(cout, generator=gen) + 0.5)
+        m.bn.bias.copy_(torch.randn(cout, generator=gen) * 0.2)
+        m.bn.running_mean.copy_(torch.randn(cout, generator=gen) * 0.3)
+        m.bn.running_var.copy_(torch.rand(cout, generator=gen) + 0.25)
+    tp = so.tcn_params_from_state(m.state_dict()).to(torch.float64)
+    x = torch.randn(N, cin, T, V, generator=gen)
+    m = m.to(dev).eval()
+    assert F.tcn_supported(cin, cout, T, V, 9, 1, F.MATH_BF16X3)
+    xd = x.to(dev)
+    with torch.no_grad():
+        set_math_mode(m, "f32_valu")
+        base = m(xd)
+        set_math_mode(m, "bf16x3")
+        m.out_bf16 = out_bf16
+        y = m(xd)
+    gate = 4e-3 if out_bf16 else 1e-4          # bf16 output: half an ulp of the stored value
+    parity_gate(y.float(), base, gate, "bf16x3 large-tile kernel vs fp32 VALU kernel", strict=not out_bf16)
+    sel = sorted({0, N // 2, N - 1})
+    ref = so.tcn_forward(x[sel].double(), tp)
+    parity_gate(y[sel].float(), ref, gate, "sampled clips vs oracle", strict=not out_bf16)
+
+
+def test_unit2d_training_step_many_tiles(dev):
+    """Training forward (raw conv through the persistent kernel, 320 tiles on 256 workgroups) and backward at a batch
+    where workgroups run more than one tile / unit, against autograd through the fp64 oracle."""
+    from stgcn_amd import Unit2D, set_math_mode
+    from oracle import stgcn_oracle as so
+    torch.manual_seed(77)
+    gen = torch.Generator().manual_seed(78)
+    m = Unit2D(128, 128, kernel_size=9)
+    with torch.no_grad():
+        m.bn.weight.copy_(torch.rand(128, generator=gen) + 0.5)
+        m.bn.bias.copy_(torch.randn(128, generator=gen) * 0.2)
+    set_math_mode(m, "bf16x3")
+    tp = so.tcn_params_from_state(m.state_dict()).to(torch.float64)
+    x = torch.randn(20, 128, 180, 22, generator=gen)
+    leaves = [tp.conv_w, tp.bn.weight, tp.bn.bias]
+    for t in leaves:
+        t.requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    yr = so.tcn_forward(xr, tp, training=True)
+    G = _kink_free_cotangent(yr, gen)
+    grads = torch.autograd.grad((yr * G.double()).sum(), leaves + [xr])
+    m = m.to(dev).train()
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    parity_gate(y.detach(), yr.detach(), 1e-4, "training-mode forward, many tiles")
+    y.backward(G.to(dev))
+    _grad_gate(m.conv.weight.grad.reshape(128, 128, 9), grads[0], 1e-4, "dW")
+    _grad_gate(m.bn.weight.grad, grads[1], 1e-4, "dgamma")
+    _grad_gate(m.bn.bias.grad, grads[2], 1e-4, "dbeta")
+    _grad_gate(xd.grad, grads[3], 1e-4, "dx")

@@ -131,22 +131,44 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
                 U[tt * Rp + r] = (r == CV && tt < tc) ? 1.f : 0.f;
             }
         }
-        // data columns: channel k, frame tt, joint v  <-  x[k][t0+tt][v]; (tt,v) advanced incrementally (no division)
+        // data columns: channel k, frame tt, joint v  <-  x[k][t0+tt][v]; (tt,v) advanced incrementally (no division).
+        // The loads of a group of 4 strides x all channels are issued together and stored afterwards: as a plain
+        // load -> store loop the fill was a chain of ~12 HBM round trips (the first fill measured 21k cycles of 120k).
         {
             const int stepT = NTH / V, stepV = NTH - stepT * V;
-            const int tt0 = tid / V, v0 = tid - tt0 * V;
-            for (int k = 0; k < Cin; ++k) {
-                const float *xk = xn + (size_t)k * xsc + (size_t)t0 * V * xsp;
-                float *ck = xcopy ? xcopy + ((size_t)n * Cin + k) * T * V + (size_t)t0 * V : nullptr;
-                int tt = tt0, v = v0;
-                for (int e = tid; e < TC * V; e += NTH) {
-                    const float xv = (tt < tc) ? xk[(size_t)e * xsp] : 0.f;
-                    U[tt * Rp + k * V + v] = xv;
-                    if (ck && tt < tc) ck[e] = xv;
+            int tt = tid / V, v = tid - tt * V;
+            constexpr int GRP = 4, KMAX = 4;         // (Cin <= 4 on this path)
+            for (int e0 = tid; e0 < TC * V; e0 += GRP * NTH) {
+                float xv[KMAX][GRP];
+                int tts[GRP], vs[GRP];
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    tts[i] = tt;
+                    vs[i] = v;
                     tt += stepT;
                     v += stepV;
                     if (v >= V) { v -= V; ++tt; }
                 }
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                    for (int i = 0; i < GRP; ++i) {
+                        const int e = e0 + i * NTH;
+                        const bool ok = k < Cin && e < TC * V && tts[i] < tc;
+                        const size_t idx = (size_t)min(k, Cin - 1) * xsc + ((size_t)t0 * V + min(e, tc * V - 1)) * xsp;
+                        const float val = xn[idx];
+                        xv[k][i] = ok ? val : 0.f;
+                    }
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                    for (int i = 0; i < GRP; ++i) {
+                        const int e = e0 + i * NTH;
+                        if (k < Cin && e < TC * V) {
+                            U[tts[i] * Rp + k * V + vs[i]] = xv[k][i];
+                            if (xcopy && tts[i] < tc) xcopy[((size_t)n * Cin + k) * T * V + (size_t)t0 * V + e] = xv[k][i];
+                        }
+                    }
             }
         }
         __syncthreads();
@@ -217,8 +239,13 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     // (the operand form of the stem kernel's matrix-core producer) -> feat[n][t*V+w] = 64 B per pixel, coalesced:
     // [hi f0-7][hi f8-15][lo f0-7][lo f8-15].
     if (feat == nullptr) return;
-    float *Xf = U;  // [3][tcf*V], reuses the dead Gram region
-    const int TCF = (R * R) / (3 * V);
+    // LDS operands of the feature loop, interleaved so that one ds_read_b128 brings what three ds_read_b32 did:
+    //   Sq[v][w] = (P_0, P_1, P_2, -)[v][w]  behind Gs and Sm;   Xq[pixel] = (x_0, x_1, x_2, -) in the dead Gram region
+    float4 *Sq = reinterpret_cast<float4 *>(U + ((R * R + S * V * V + 3) & ~3));
+    float4 *Xq = reinterpret_cast<float4 *>(U);
+    const int TCF = (R * R) / (4 * V);
+    __syncthreads();  // P complete in Sm
+    for (int e = tid; e < V * V; e += NTH) Sq[e] = make_float4(Sm[e], Sm[V * V + e], Sm[2 * V * V + e], 0.f);
     // Each lane builds one 64-byte feature row; storing it directly is 16 B per lane at a 64-B stride (store-issue
     // bound, measured ~4 B/clk/CU).  Instead the wave parks its 64 rows (4 KiB) in a private LDS slice and writes
     // them back out lane-linear: four fully coalesced 1-KiB stores.
@@ -228,10 +255,10 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     for (int t0 = 0; t0 < T; t0 += TCF) {
         const int tcf = min(TCF, T - t0);
         const int px = tcf * V;
-        __syncthreads();  // P complete in Sm / previous chunk consumed
-        for (int k = 0; k < 3; ++k) {
-            const float *xk = xn + (size_t)k * xsc + (size_t)t0 * V * xsp;
-            for (int e = tid; e < px; e += NTH) Xf[k * px + e] = xk[(size_t)e * xsp];
+        __syncthreads();  // Sq complete / previous chunk consumed
+        for (int e = tid; e < px; e += NTH) {
+            const size_t g = ((size_t)t0 * V + e) * xsp;
+            Xq[e] = make_float4(xn[g], xn[(size_t)xsc + g], xn[2 * (size_t)xsc + g], 0.f);
         }
         __syncthreads();
         for (int p0 = (tid & ~63); p0 < px; p0 += NTH) {   // 64 consecutive pixels per wave
@@ -241,19 +268,19 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
                 float u[9];
 #pragma unroll
                 for (int f = 0; f < 9; ++f) u[f] = 0.f;
+                const float4 *xr = Xq + tt * V;
+                const float4 *pr = Sq + w;
 #pragma unroll 2
                 for (int v = 0; v < V; ++v) {
-                    const float x0 = Xf[tt * V + v], x1 = Xf[px + tt * V + v], x2 = Xf[2 * px + tt * V + v];
-#pragma unroll
-                    for (int s3 = 0; s3 < 3; ++s3) {
-                        const float pw = Sm[(s3 * V + v) * V + w];
-                        u[s3 * 3 + 0] = fmaf(x0, pw, u[s3 * 3 + 0]);
-                        u[s3 * 3 + 1] = fmaf(x1, pw, u[s3 * 3 + 1]);
-                        u[s3 * 3 + 2] = fmaf(x2, pw, u[s3 * 3 + 2]);
-                    }
+                    const float4 xv = xr[v];
+                    const float4 pv = pr[v * V];
+                    u[0] = fmaf(xv.x, pv.x, u[0]); u[1] = fmaf(xv.y, pv.x, u[1]); u[2] = fmaf(xv.z, pv.x, u[2]);
+                    u[3] = fmaf(xv.x, pv.y, u[3]); u[4] = fmaf(xv.y, pv.y, u[4]); u[5] = fmaf(xv.z, pv.y, u[5]);
+                    u[6] = fmaf(xv.x, pv.z, u[6]); u[7] = fmaf(xv.y, pv.z, u[7]); u[8] = fmaf(xv.z, pv.z, u[8]);
                 }
+                const float4 xp = Xq[p];
                 const float fa[8] = {u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]};
-                const float fb[8] = {u[8], Xf[p], Xf[px + p], Xf[2 * px + p], 1.f, 0.f, 0.f, 0.f};
+                const float fb[8] = {u[8], xp.x, xp.y, xp.z, 1.f, 0.f, 0.f, 0.f};
                 uint4 ha, la, hb, lb;  // bf16 hi / lo residual of features 0-7 and 8-15
                 bf16k::split8(fa, ha, la);
                 bf16k::split8(fb, hb, lb);
@@ -362,7 +389,7 @@ static FoldedPlan plan_folded(int Cin, int T, int V, int inter_c, int S, bool wi
     const int C1 = Cin + 1, R = Cin * V + 1;
     const int nTr = ceil_div(R, TM), nTc = ceil_div(R, TN);
     const int ntiles = nTr * nTc;
-    const size_t gs_floats = (size_t)R * R + (size_t)S * V * V;
+    const size_t gs_floats = (size_t)R * R + (size_t)S * V * V + (with_features ? (size_t)4 * V * V + 4 : 0);   // Gram, P, interleaved P
     if (Cin > 4 || S * C1 * C1 > MS_FLOATS || ntiles > 8 * 256) return pl;
     if (with_features && (Cin != 3 || S != 3)) return pl;
     pl.maxit = ceil_div(ntiles, 256);

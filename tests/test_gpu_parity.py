@@ -759,3 +759,65 @@ def test_unit2d_training_step_many_tiles(dev):
     _grad_gate(m.bn.weight.grad, grads[1], 1e-4, "dgamma")
     _grad_gate(m.bn.bias.grad, grads[2], 1e-4, "dbeta")
     _grad_gate(xd.grad, grads[3], 1e-4, "dx")
+
+
+@pytest.mark.parametrize("N,T,V", [(2, 1, 22), (1, 3, 46), (3, 9, 7)])
+def test_training_step_degenerate_shapes(N, T, V, dev):
+    """T = 1, single clip, narrow frames: forward + backward of both modules still agree with the fp64 oracle."""
+    from oracle import stgcn_oracle as so
+    gcn, tcn, gp, tp, gen = _random_stem(V, None, 1300 + T + V, dev)
+    gp, tp = gp.to(torch.float64), tp.to(torch.float64)
+    leaves = _agcn_oracle_leaves(gp)
+    x = torch.randn(N, 3, T, V, generator=gen)
+    hr = so.agcn_forward(x.double(), gp, training=True)
+    G = _kink_free_cotangent(hr, gen)
+    names = sorted(leaves)
+    ref = dict(zip(names, torch.autograd.grad((hr * G.double()).sum(), [leaves[k] for k in names])))
+    gcn.train()
+    h = gcn(x.to(dev))
+    parity_gate(h.detach(), hr.detach(), 1e-4, "graph conv, training forward")
+    h.backward(G.to(dev))
+    _compare_grads(_agcn_module_grads(gcn), ref, 1e-4)
+    # temporal block on the same degenerate shape
+    tl = [tp.conv_w, tp.bn.weight, tp.bn.bias]
+    for t in tl:
+        t.requires_grad_(True)
+    xin = torch.randn(N, 128, T, V, generator=gen)
+    xr = xin.double().requires_grad_(True)
+    zr = so.tcn_forward(xr, tp, training=True)
+    G2 = _kink_free_cotangent(zr, gen)
+    g2 = torch.autograd.grad((zr * G2.double()).sum(), tl + [xr])
+    tcn.train()
+    xd = xin.to(dev).requires_grad_(True)
+    z = tcn(xd)
+    parity_gate(z.detach(), zr.detach(), 1e-4, "temporal block, training forward")
+    z.backward(G2.to(dev))
+    _grad_gate(tcn.conv.weight.grad.reshape(128, 128, 9), g2[0], 1e-4, "dW")
+    _grad_gate(tcn.bn.weight.grad, g2[1], 1e-4, "dgamma")
+    _grad_gate(xd.grad, g2[3], 1e-4, "dx")
+
+
+def test_unit2d_backward_bf16_mode(dev):
+    """STGCN_MATH_BF16 (operands rounded to bf16, the documented 1e-2 mode) also drives the backward kernels."""
+    from stgcn_amd import Unit2D, set_math_mode
+    from oracle import stgcn_oracle as so
+    torch.manual_seed(31)
+    gen = torch.Generator().manual_seed(32)
+    m = Unit2D(128, 128, kernel_size=9)
+    set_math_mode(m, "bf16")
+    tp = so.tcn_params_from_state(m.state_dict()).to(torch.float64)
+    x = torch.randn(3, 128, 30, 22, generator=gen)
+    leaves = [tp.conv_w, tp.bn.weight, tp.bn.bias]
+    for t in leaves:
+        t.requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    yr = so.tcn_forward(xr, tp, training=True)
+    G = torch.randn(yr.shape, generator=gen) * (yr.detach() > 2e-2 * yr.detach().abs().max()).float()
+    grads = torch.autograd.grad((yr * G.double()).sum(), leaves + [xr])
+    m = m.to(dev).train()
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    parity_gate(y.detach(), yr.detach(), 1e-2, "bf16 training forward", strict=False)
+    y.backward(G.to(dev))
+    _grad_gate(m.conv.weight.grad.reshape(128, 128, 9), grads[0], 2e-2, "dW")
+    _grad_gate(xd.grad, grads[3], 2e-2, "dx")

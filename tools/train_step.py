@@ -18,9 +18,10 @@ ap.add_argument("--clips", type=int, default=256); ap.add_argument("--frames", t
 ap.add_argument("--math", default="bf16x3"); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
 a = ap.parse_args()
 local = int(os.environ.get("LOCAL_RANK", "0"))
-dev = torch.device("cuda", local)
+backend = os.environ.get("STGCN_DIST_BACKEND", "nccl")   # gloo + fewer GPUs than ranks: rehearsal on a 1-GPU box
+dev = torch.device("cuda", local if backend == "nccl" else local % max(torch.cuda.device_count(), 1))
 torch.cuda.set_device(dev)
-rank, world = sd.init(device=dev)
+rank, world = sd.init(backend, dev)
 gcn, tcn = bench.build_stem(22, "SHRE", a.math)
 gcn, tcn = gcn.to(dev).train(), tcn.to(dev).train()
 x = bench.synthetic_clips(a.clips, a.frames, 22, seed=rank).to(dev)

@@ -111,8 +111,10 @@ def profiled_traffic(kernel_prefix, default_config):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed steps; the default is long enough (~0.2 s) for the GPU clocks to settle: 20-step runs measure the "
+                         "ramp after idle and read ~12 %% low (DESIGN.md section 5)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--clips-per-gpu", type=int, default=256, help="256 = BASELINE configs[1]; 1024 = configs[4] at 8 GPUs")
     ap.add_argument("--frames", type=int, default=180)
     ap.add_argument("--graph", choices=["SHRE", "LMDHG"], default="SHRE")

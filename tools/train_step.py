@@ -3,7 +3,7 @@
 to the stem) — on synthetic clips; prints one JSON line.  Optional data-parallel run under torchrun (one flat-bucket
 gradient all-reduce per step).  Secondary measurement: bench.py's headline stays the eval forward.
 
-    python tools/train_step.py [--clips 256] [--math bf16x3] [--steps 10]
+    python tools/train_step.py [--clips 256] [--math bf16x3] [--steps 60]
 """
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ from stgcn_amd import dist as sd
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--clips", type=int, default=256); ap.add_argument("--frames", type=int, default=180)
-ap.add_argument("--math", default="bf16x3"); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--math", default="bf16x3"); ap.add_argument("--steps", type=int, default=60); ap.add_argument("--warmup", type=int, default=15)
 a = ap.parse_args()
 local = int(os.environ.get("LOCAL_RANK", "0"))
 backend = os.environ.get("STGCN_DIST_BACKEND", "nccl")   # gloo + fewer GPUs than ranks: rehearsal on a 1-GPU box

@@ -24,7 +24,8 @@
 //                 MFMAs (tap loop fully unrolled for K = 9).  Stand-alone temporal conv (tcn_mfma_bf16_kernel):
 //                 fp32 activations loaded from HBM/L2, coalesced along pixels, split and stored by the VALU.
 //                 Fused stem at 128-pixel tiles (stem_mfma_bf16_kernel): relu(W12 . features) on the matrix cores
-//                 from an LDS feature tile; the 256-pixel persistent form lives in stem_bf16_v4.hip.
+//                 from an LDS feature tile; the 256-pixel persistent forms (fused stem KF4, and K3v4 for the stand-alone
+//                 K = 9 / stride 1 block, which this file's kernel serves for every other shape) live in stem_bf16_v4.hip.
 #include "bf16_common.h"
 
 namespace stgcn {

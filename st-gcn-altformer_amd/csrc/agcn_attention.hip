@@ -240,10 +240,10 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     // [hi f0-7][hi f8-15][lo f0-7][lo f8-15].
     if (feat == nullptr) return;
     // LDS operands of the feature loop, interleaved so that one ds_read_b128 brings what three ds_read_b32 did:
-    //   Sq[v][w] = (P_0, P_1, P_2, -)[v][w]  behind Gs and Sm;   Xq[pixel] = (x_0, x_1, x_2, -) in the dead Gram region
-    float4 *Sq = reinterpret_cast<float4 *>(U + ((R * R + S * V * V + 3) & ~3));
-    float4 *Xq = reinterpret_cast<float4 *>(U);
-    const int TCF = (R * R) / (4 * V);
+    //   Sq[v][w] = (P_0, P_1, P_2, -)[v][w]  and  Xq[pixel] = (x_0, x_1, x_2, -), both in the dead Gram region
+    float4 *Sq = reinterpret_cast<float4 *>(U);
+    float4 *Xq = Sq + V * V;
+    const int TCF = (R * R - 4 * V * V) / (4 * V);   // (R*R = (3V+1)^2 > 9 V^2: always at least one frame)
     __syncthreads();  // P complete in Sm
     for (int e = tid; e < V * V; e += NTH) Sq[e] = make_float4(Sm[e], Sm[V * V + e], Sm[2 * V * V + e], 0.f);
     // Each lane builds one 64-byte feature row; storing it directly is 16 B per lane at a 64-B stride (store-issue
@@ -384,16 +384,16 @@ struct FoldedPlan {
     size_t lds = 0;
 };
 
-static FoldedPlan plan_folded(int Cin, int T, int V, int inter_c, int S, bool with_features) {
+static FoldedPlan plan_folded_ts(int Cin, int T, int V, int inter_c, int S, bool with_features, int ts) {
     FoldedPlan pl;
     const int C1 = Cin + 1, R = Cin * V + 1;
     const int nTr = ceil_div(R, TM), nTc = ceil_div(R, TN);
     const int ntiles = nTr * nTc;
-    const size_t gs_floats = (size_t)R * R + (size_t)S * V * V + (with_features ? (size_t)4 * V * V + 4 : 0);   // Gram, P, interleaved P
+    const size_t gs_floats = (size_t)R * R + (size_t)S * V * V;
     if (Cin > 4 || S * C1 * C1 > MS_FLOATS || ntiles > 8 * 256) return pl;
     if (with_features && (Cin != 3 || S != 3)) return pl;
     pl.maxit = ceil_div(ntiles, 256);
-    pl.ts = pl.maxit <= 4 ? 4 : 2;                           // time slices: 1024 or 512 threads
+    pl.ts = ts;                                              // time slices: 1024 or 512 threads
     pl.Rp = (nTr * TM > nTc * TN ? nTr * TM : nTc * TN) | 1; // odd row stride spreads the tile reads over banks
     const size_t slices = with_features ? (size_t)4 * pl.ts * 4096 : 0;   // 4 KiB per wave for the coalesced feature rows
     // chunk of frames held in LDS: the whole clip when it fits in ~96 KiB, else as many frames as do
@@ -414,6 +414,17 @@ static FoldedPlan plan_folded(int Cin, int T, int V, int inter_c, int S, bool wi
     pl.lds = (MS_FLOATS + u_floats) * 4 + slices;
     pl.ok = pl.lds <= (size_t)kLdsBytes;
     return pl;
+}
+
+// 1024 threads (4 time slices) where the register tiles and LDS allow, else 512 (wide frames: V = 46 with features)
+static FoldedPlan plan_folded(int Cin, int T, int V, int inter_c, int S, bool with_features) {
+    const int R = Cin * V + 1;
+    const int maxit = ceil_div(ceil_div(R, TM) * ceil_div(R, TN), 256);
+    if (maxit <= 4) {
+        const FoldedPlan p4 = plan_folded_ts(Cin, T, V, inter_c, S, with_features, 4);
+        if (p4.ok) return p4;
+    }
+    return plan_folded_ts(Cin, T, V, inter_c, S, with_features, 2);
 }
 
 // true when launch_attention can also emit the (N, T*V, 16) feature tensor (folded kernel, Cin = 3, S = 3)
@@ -439,10 +450,14 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
         hipLaunchKernelGGL((attention_folded_kernel<MI, TSL>), dim3(N), dim3(256 * TSL), lds, st, x, A_eff, \
                            Wa, ba, Wb, bb, P, feat, Cin, T, V, inter_c, S, TC, Rp, slice_off, xsc, xsp, xcopy, debug_buffer()); \
     } while (0)
-        if (pl.maxit <= 1) LAUNCH_FOLDED(1, 4);
-        else if (pl.maxit <= 2) LAUNCH_FOLDED(2, 4);
-        else if (pl.maxit <= 4) LAUNCH_FOLDED(4, 4);
-        else LAUNCH_FOLDED(8, 2);
+        if (pl.ts == 4) {
+            if (pl.maxit <= 1) LAUNCH_FOLDED(1, 4);
+            else if (pl.maxit <= 2) LAUNCH_FOLDED(2, 4);
+            else LAUNCH_FOLDED(4, 4);
+        } else {
+            if (pl.maxit <= 4) LAUNCH_FOLDED(4, 2);
+            else LAUNCH_FOLDED(8, 2);
+        }
 #undef LAUNCH_FOLDED
         STGCN_LAUNCH_CHECK("attention_folded_kernel");
         return STGCN_OK;

@@ -107,5 +107,28 @@ __device__ __forceinline__ void mfma_half_bf16(f32x16 (&acc)[2][2], const Frag2<
     }
 }
 
+// B-side operands of one k-step for NJ pixel blocks, and the half-step on a 2 x NJ accumulator tile
+template <int TERMS, int NJ>
+struct FragB {
+    uint4 hi[NJ];
+    uint4 lo[TERMS == 3 ? NJ : 1];
+};
+
+template <int TERMS, int NJ>
+__device__ __forceinline__ void mfma_half_bf16(f32x16 (&acc)[2][NJ], const Frag2<TERMS> &a, const FragB<TERMS, NJ> &b, int m) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a.hi[m]);
+#pragma unroll
+    for (int n = 0; n < NJ; ++n) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi[n]);
+        if constexpr (TERMS == 3) {
+            const bf16x8 al = __builtin_bit_cast(bf16x8, a.lo[m]);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, b.lo[n]);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m][n], 0, 0, 0);
+        }
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m][n], 0, 0, 0);
+    }
+}
+
 }  // namespace bf16k
 }  // namespace stgcn

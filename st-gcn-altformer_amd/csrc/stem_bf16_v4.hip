@@ -29,7 +29,7 @@ namespace {
 
 using namespace bf16k;
 
-constexpr int NP4 = 256;   // output pixels per tile
+constexpr int NP4 = 256;   // output pixels per tile (NJ = 2; the narrow form of the fused kernel uses 128)
 constexpr int NT4 = 512;   // threads per workgroup
 constexpr int KT4 = 9;     // temporal taps (the only kernel size this kernel is built for)
 constexpr int STG = 3;     // taps per weight stage
@@ -56,7 +56,10 @@ __device__ __forceinline__ void dma16(const void *g, unsigned lds_addr) {  // ld
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int PB, int TERMS, bool BF16OUT>
+// NJ = 32-pixel blocks per wave: 2 -> 256-pixel tile (the form described above); 1 -> 128-pixel tile for wide frames
+// (V = 46: the 256-pixel tile's rows do not fit LDS).  With NJ = 1 the folded graph-conv matrix is not copied to LDS
+// (the producer reads its rows through L1 and splits them in registers), which is what makes the tile fit.
+template <int PB, int TERMS, bool BF16OUT, int NJ>
 __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     const float4 *__restrict__ feat, const float *__restrict__ W12, const uint4 *__restrict__ Wp,
     const float *__restrict__ shift, void *y, int C, int T, int V, int ROWS, int tiles_per_clip, int ntiles,
@@ -74,6 +77,8 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
+    constexpr int NPX = 128 * NJ;            // output pixels per tile
+    constexpr bool W12LDS = NJ == 2;
     const int TV = T * V;
     const int nch = C / CCB;                 // channel chunks (C = 128 -> 8)
     const int nstage = nch * (KT4 / STG);    // weight stages per tile
@@ -81,12 +86,12 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     const int buf_bytes = img_bytes * (TERMS == 3 ? 2 : 1);
     // LDS carve
     uint4 *W12q = reinterpret_cast<uint4 *>(smem4);                 // folded graph conv as bf16 hi/lo: 4 planes of [C] x 16 B
-    char *ring = smem4 + C * W12P * 4;                              // 2 stages x 3 taps x 8 fragments
+    char *ring = smem4 + (W12LDS ? C * W12P * 4 : 0);               // 2 stages x 3 taps x 8 fragments
     char *buf0 = ring + 2 * STAGE_BYTES;
     char *buf1 = buf0 + buf_bytes;
     // (the image buffers double as the epilogue's staging area, 8 KiB per wave; the feature tile is prefetched for
     //  the next tile while that epilogue runs, so it starts behind BOTH)
-    uint4 *Fs = reinterpret_cast<uint4 *>(buf0 + max(2 * buf_bytes, 8 * EPI_BYTES));  // features as bf16 hi/lo: 4 planes of [ROWS] x 16 B
+    uint4 *Fs = reinterpret_cast<uint4 *>(buf0 + max(2 * buf_bytes, 8 * EPI_BYTES * NJ / 2));  // features as bf16 hi/lo: 4 planes of [ROWS] x 16 B
     // LDS byte addresses for the DMA destinations (M0), derived from the array base by plain arithmetic
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem4;
     const unsigned ring_lds = lds0 + (unsigned)(ring - smem4);
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     // feature rows of tile `tile` -> Fs (rows whose pixel lies outside the clip are fixed up afterwards)
     auto dma_features = [&](int tile) {
         const int n = tile / tiles_per_clip;
-        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NP4);
+        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NPX);
         const float4 *src = feat + (size_t)n * TV * 4;
         for (int c = wave * 64; c < 4 * ROWS; c += 8 * 64) {       // chunk c = plane q, rows j0 .. j0+63
             const int q = c / ROWS, j = c - q * ROWS + lane;       // ROWS % 64 == 0
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     };
     auto zero_invalid_rows = [&](int tile) {
         const int n = tile / tiles_per_clip;
-        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NP4);
+        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NPX);
         for (int j = tid; j < ROWS; j += NT4) {
             const int gi = g.origin + j;
             if (j >= g.span || gi < 0 || gi >= TV) {
@@ -138,8 +143,15 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     struct Prod { uint4 wh, wl, fb; f32x4 d; int p; };
     auto prod_load = [&](Prod &pr, int ch, int bi) {
         pr.p = bi * 16 + pl;
-        pr.wh = W12q[(size_t)(pg & 1) * C + ch * CCB + pl];
-        pr.wl = W12q[(size_t)(2 + (pg & 1)) * C + ch * CCB + pl];
+        if constexpr (W12LDS) {
+            pr.wh = W12q[(size_t)(pg & 1) * C + ch * CCB + pl];
+            pr.wl = W12q[(size_t)(2 + (pg & 1)) * C + ch * CCB + pl];
+        } else {
+            const float4 *wr = reinterpret_cast<const float4 *>(W12 + (size_t)(ch * CCB + pl) * W12P + (pg & 1) * 8);
+            const float4 w0 = wr[0], w1 = wr[1];
+            const float w8[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            split8(w8, pr.wh, pr.wl);
+        }
         pr.fb = Fs[(size_t)pg * ROWS + pr.p];
     };
     auto prod_mfma = [&](Prod &pr) {
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         prod_finish(buf, pr);
     };
     // ---- one-time setup ----------------------------------------------------------------------
-    for (int e = tid; e < C * 2; e += NT4) {  // W12 -> bf16 hi/lo, planes [hi k0-7][hi k8-15][lo k0-7][lo k8-15] of [C] x 16 B
+    for (int e = tid; e < (W12LDS ? C * 2 : 0); e += NT4) {  // W12 -> bf16 hi/lo, planes [hi k0-7][hi k8-15][lo k0-7][lo k8-15] of [C] x 16 B
         const int c = e >> 1, kh = e & 1;
         float w8[8];
 #pragma unroll
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     const int h = lane >> 5;
     for (; tile < ntiles; tile += gridDim.x) {
         const int n = tile / tiles_per_clip;
-        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NP4);
+        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NPX);
         const int nblk = (g.span + 15) >> 4;
         const int next_tile = tile + gridDim.x;
 
@@ -203,19 +215,19 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         // chunk 0 of this tile
         for (int b = wave; b < nblk; b += 8) produce_block(buf0, 0, b);
 
-        int prow[2];
+        int prow[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int q = g.q0 + (wn * 2 + j) * 32 + (lane & 31);
+        for (int j = 0; j < NJ; ++j) {
+            int q = g.q0 + (wn * NJ + j) * 32 + (lane & 31);
             q = min(q, g.q_last);
             const int t = q / V, v = q - t * V;
             prow[j] = (t - g.t_first) * V + v;
         }
-        f32x16 acc[2][2];
+        f32x16 acc[2][NJ];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
         __syncthreads();                      // chunk 0 visible
@@ -231,10 +243,10 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                 if constexpr (TERMS == 3) a.lo[m] = *reinterpret_cast<const uint4 *>(aslot + (tt * 8 + m * 2 + 1) * FRAG);
             }
         };
-        auto load_b = [&](Frag2<TERMS> &b, const char *img, int tap) {
+        auto load_b = [&](FragB<TERMS, NJ> &b, const char *img, int tap) {
             if (STGCN_ABL(8)) return;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int off = lds_off(prow[j] + tap * V, h);
                 b.hi[j] = *reinterpret_cast<const uint4 *>(img + off);
                 if constexpr (TERMS == 3) b.lo[j] = *reinterpret_cast<const uint4 *>(img + img_bytes + off);
@@ -249,7 +261,8 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         //  other producer/DMA taps for waves 4-7 and a static s_setprio for that half: neutral.  The kernel is
         //  clock-limited under load — tools/power_probe.py: 17 % faster on zero operands, same instruction stream —
         //  so removed stalls come back partly as a lower clock.)
-        Frag2<TERMS> a_cur = {}, b_cur = {}, a_nxt = {}, b_nxt = {};
+        Frag2<TERMS> a_cur = {}, a_nxt = {};
+        FragB<TERMS, NJ> b_cur = {}, b_nxt = {};
         for (int ch = 0; ch < nch; ++ch) {
             const char *cur = (ch & 1) ? buf1 : buf0;
             char *nxt = (ch & 1) ? buf0 : buf1;
@@ -275,14 +288,14 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                     if (tt + 1 < STG) load_a(a_nxt, aslot, tt + 1);
                     if (tap + 1 < KT4) load_b(b_nxt, cur, tap + 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!STGCN_ABL(2)) mfma_half_bf16<TERMS>(acc, a_cur, b_cur, 0);
+                    if (!STGCN_ABL(2)) mfma_half_bf16<TERMS, NJ>(acc, a_cur, b_cur, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (prod) prod_mfma(pr);
                     // next weight stage -> other ring slot (its readers passed the last barrier); issued behind the
                     // first MFMAs so the DMA's issue cost does not delay the start of the stage
                     if (tt == 0) dma_stage(gs + 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!STGCN_ABL(2)) mfma_half_bf16<TERMS>(acc, a_cur, b_cur, 1);
+                    if (!STGCN_ABL(2)) mfma_half_bf16<TERMS, NJ>(acc, a_cur, b_cur, 1);
                     __builtin_amdgcn_sched_barrier(0);
                     if (prod) prod_finish(nxt, pr);
                     a_cur = a_nxt;
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             // (N,T,V,C) output: the block is staged pixel-major ([64 pixels][32 channels], 16-byte slots XOR-swizzled by
             // the pixel so the b128 accesses are conflict-free); a wave-instruction then writes 8 pixels x 128 B.
             float *stg = reinterpret_cast<float *>(buf0 + wave * EPI_BYTES);
-            const int qw = g.q0 + wn * 64;
+            const int qw = g.q0 + wn * 32 * NJ;
             const int hh = lane >> 5;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                     }
                 }
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
+                for (int it = 0; it < 4 * NJ; ++it) {
                     const int idx = it * 64 + lane, px = idx >> 3, sl = idx & 7;
                     const float4 v = *reinterpret_cast<const float4 *>(stg + px * 32 + ((sl ^ (px & 7)) << 2));
                     const int q = qw + px;
@@ -340,7 +353,8 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             }
         } else if (!STGCN_ABL(4)) {
             float *stg = reinterpret_cast<float *>(buf0 + wave * EPI_BYTES);
-            const int qw = g.q0 + wn * 64;                       // first pixel of this wave's 64 columns
+            constexpr int PW = 32 * NJ;                          // pixel columns of this wave
+            const int qw = g.q0 + wn * PW;                       // first of them
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int ob = cg * 128 + (wm * 2 + m) * 32;     // first output channel of the block
@@ -349,12 +363,12 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                     const int cr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const float sh = shift[ob + cr];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) stg[cr * 64 + j * 32 + (lane & 31)] = fmaxf(acc[m][j][r] + sh, 0.f);
+                    for (int j = 0; j < NJ; ++j) stg[cr * PW + j * 32 + (lane & 31)] = fmaxf(acc[m][j][r] + sh, 0.f);
                 }
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int idx = it * 64 + lane, row = idx >> 4, c4 = (idx & 15) * 4;
-                    const float4 v = *reinterpret_cast<const float4 *>(stg + row * 64 + c4);
+                for (int it = 0; it < 4 * NJ; ++it) {
+                    const int idx = it * 64 + lane, row = idx / (PW / 4), c4 = (idx % (PW / 4)) * 4;
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + row * PW + c4);
                     const int q = qw + c4;
                     const size_t gidx = ((size_t)n * C + ob + row) * TV + q;
                     if (q + 3 <= g.q_last && (!BF16OUT || (gidx & 1) == 0)) {  // (bf16: keep the 8-B store dword-aligned)
@@ -615,42 +629,50 @@ __global__ __launch_bounds__(NT4) void tcn_bf16_v4_kernel(
 }
 
 struct V4Plan {
-    int pb = 0, rows = 0, tiles_per_clip = 0;
+    int pb = 0, rows = 0, tiles_per_clip = 0, nj = 0;
     size_t lds = 0;
 };
 
-inline bool plan_v4(int C, int T, int V, int K, int terms, V4Plan &pl) {
+inline bool plan_v4_nj(int C, int T, int V, int K, int terms, int nj, V4Plan &pl) {
     if (K != KT4 || C % 128 != 0) return false;
-    int dt = ceil_div(NP4 - 1, V);
+    const int np = 128 * nj;
+    int dt = ceil_div(np - 1, V);
     if (dt > T - 1) dt = T - 1;
     const int span = (dt + K) * V;
     const int rows = (span + 63) / 64 * 64;          // feature DMA moves 64 rows per wave-instruction
     const int pb = ceil_div(ceil_div(span, 16), 8);  // producer blocks per wave per chunk (8 producing waves)
     if (pb > KT4) return false;
     const size_t buf = (size_t)rows * PXB * (terms == 3 ? 2 : 1);
-    const size_t img = 2 * buf > (size_t)8 * EPI_BYTES ? 2 * buf : (size_t)8 * EPI_BYTES;  // images / epilogue staging
-    const size_t lds = (size_t)C * W12P * 4 + 2 * STAGE_BYTES + img + (size_t)rows * 64;
+    const size_t stage = (size_t)8 * EPI_BYTES * nj / 2;                       // epilogue staging: 8 waves x 32 ch x 32*nj px
+    const size_t img = 2 * buf > stage ? 2 * buf : stage;                      // images / epilogue staging
+    const size_t lds = (nj == 2 ? (size_t)C * W12P * 4 : 0) + 2 * STAGE_BYTES + img + (size_t)rows * 64;
     if (lds > (size_t)kLdsBytes) return false;
     pl.pb = pb;
     pl.rows = rows;
-    pl.tiles_per_clip = ceil_div(T * V, NP4);
+    pl.tiles_per_clip = ceil_div(T * V, np);
+    pl.nj = nj;
     pl.lds = lds;
     return true;
 }
 
-template <int PB, int TERMS>
+// the 256-pixel tile where its rows fit LDS (V <= ~25), else the 128-pixel tile (V = 46)
+inline bool plan_v4(int C, int T, int V, int K, int terms, V4Plan &pl) {
+    return plan_v4_nj(C, T, V, K, terms, 2, pl) || plan_v4_nj(C, T, V, K, terms, 1, pl);
+}
+
+template <int PB, int TERMS, int NJ>
 int launch_v4(const float4 *feat, const float *W12, const uint4 *Wp, const float *shift, void *y, int N, int C, int T,
               int V, const V4Plan &pl, bool bf16out, int opt, int num_cu, hipStream_t st) {
     const int ntiles = N * pl.tiles_per_clip;
     const int gx = ntiles < num_cu ? ntiles : num_cu;
     const dim3 grid(gx, C / 128, 1);
     if (bf16out) {
-        auto kern = stem_bf16_v4_kernel<PB, TERMS, true>;
+        auto kern = stem_bf16_v4_kernel<PB, TERMS, true, NJ>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
                            pl.tiles_per_clip, ntiles, ablate_mask() | opt, debug_buffer());
     } else {
-        auto kern = stem_bf16_v4_kernel<PB, TERMS, false>;
+        auto kern = stem_bf16_v4_kernel<PB, TERMS, false, NJ>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
                            pl.tiles_per_clip, ntiles, ablate_mask() | opt, debug_buffer());
@@ -742,12 +764,16 @@ int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, cons
     const float4 *f4 = (const float4 *)feat;
     const float *W12 = (const float *)prep_w12;
     const uint4 *wp = (const uint4 *)Wp;
-#define GO(PB)                                                                                                  \
-    return terms == 3 ? launch_v4<PB, 3>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, opt, num_cu, st)     \
-                      : launch_v4<PB, 1>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, opt, num_cu, st)
-    if (pl.pb <= 4) GO(4);
-    if (pl.pb <= 6) GO(6);
-    GO(9);
+#define GO(PB, NJ)                                                                                              \
+    return terms == 3 ? launch_v4<PB, 3, NJ>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, opt, num_cu, st)     \
+                      : launch_v4<PB, 1, NJ>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, opt, num_cu, st)
+    if (pl.nj == 1) {
+        if (pl.pb <= 6) GO(6, 1);
+        GO(9, 1);
+    }
+    if (pl.pb <= 4) GO(4, 2);
+    if (pl.pb <= 6) GO(6, 2);
+    GO(9, 2);
 #undef GO
 }
 

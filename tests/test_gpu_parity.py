@@ -821,3 +821,22 @@ def test_unit2d_backward_bf16_mode(dev):
     y.backward(G.to(dev))
     _grad_gate(m.conv.weight.grad.reshape(128, 128, 9), grads[0], 2e-2, "dW")
     _grad_gate(xd.grad, grads[3], 2e-2, "dx")
+
+
+def test_unit_agcn_backward_more_clips_than_workgroups(dev):
+    """N = 300 clips on the 256-workgroup grid of the graph-conv backward: 44 workgroups process two clips, so the
+    per-workgroup accumulators (weight gradients, dPA, dM) carry over from one clip to the next."""
+    from oracle import stgcn_oracle as so
+    gcn, _, gp, _, gen = _random_stem(22, None, 1400, dev)
+    gp = gp.to(torch.float64)
+    leaves = _agcn_oracle_leaves(gp)
+    x = torch.randn(300, 3, 6, 22, generator=gen)
+    yr = so.agcn_forward(x.double(), gp, training=True)
+    G = _kink_free_cotangent(yr, gen)
+    names = sorted(leaves)
+    ref = dict(zip(names, torch.autograd.grad((yr * G.double()).sum(), [leaves[k] for k in names])))
+    gcn.train()
+    y = gcn(x.to(dev))
+    parity_gate(y.detach(), yr.detach(), 1e-4, "training-mode forward, 300 clips")
+    y.backward(G.to(dev))
+    _compare_grads(_agcn_module_grads(gcn), ref, 1e-4)

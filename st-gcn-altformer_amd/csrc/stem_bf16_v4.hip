@@ -316,9 +316,9 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         // wave-instruction writes four 256-B channel rows.
         STGCN_STAMP(t_e0)
         if (!STGCN_ABL(4) && (abl & OPT_OUT_NTVC)) {
-            // (N,T,V,C) output: the block is staged pixel-major ([64 pixels][32 channels], 16-byte slots XOR-swizzled by
+            // (N,T,V,C) output: the block is staged pixel-major ([32*NJ pixels][32 channels], 16-byte slots XOR-swizzled by
             // the pixel so the b128 accesses are conflict-free); a wave-instruction then writes 8 pixels x 128 B.
-            float *stg = reinterpret_cast<float *>(buf0 + wave * EPI_BYTES);
+            float *stg = reinterpret_cast<float *>(buf0 + wave * (EPI_BYTES * NJ / 2));   // 32 ch x 32*NJ px per wave
             const int qw = g.q0 + wn * 32 * NJ;
             const int hh = lane >> 5;
 #pragma unroll
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                 for (int gq = 0; gq < 4; ++gq) {
                     const float4 sh4 = *reinterpret_cast<const float4 *>(shift + ob + 8 * gq + 4 * hh);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         const int px = j * 32 + (lane & 31);
                         const float4 v = make_float4(fmaxf(acc[m][j][4 * gq + 0] + sh4.x, 0.f), fmaxf(acc[m][j][4 * gq + 1] + sh4.y, 0.f),
                                                      fmaxf(acc[m][j][4 * gq + 2] + sh4.z, 0.f), fmaxf(acc[m][j][4 * gq + 3] + sh4.w, 0.f));
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                 }
             }
         } else if (!STGCN_ABL(4)) {
-            float *stg = reinterpret_cast<float *>(buf0 + wave * EPI_BYTES);
+            float *stg = reinterpret_cast<float *>(buf0 + wave * (EPI_BYTES * NJ / 2));   // 32 ch x 32*NJ px per wave
             constexpr int PW = 32 * NJ;                          // pixel columns of this wave
             const int qw = g.q0 + wn * PW;                       // first of them
 #pragma unroll

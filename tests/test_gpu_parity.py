@@ -405,7 +405,8 @@ def test_persistent_kernel_uneven_tiles(N, dev):
 
 
 @pytest.mark.parametrize("math,N,T,V", [("bf16", 40, 180, 22), ("bf16x3", 80, 300, 7), ("bf16x3", 48, 90, 25),
-                                        ("bf16", 80, 300, 7)])
+                                        ("bf16", 80, 300, 7),
+                                        ("bf16x3", 24, 60, 46), ("bf16", 24, 60, 46), ("bf16x3", 30, 50, 30)])   # 128-pixel tile form
 def test_persistent_kernel_many_tiles_small_images(math, N, T, V, dev):
     """Every workgroup of the persistent kernel runs several tiles at shapes whose LDS image buffers are smaller
     than at the BASELINE shape (narrow V, or one image per buffer in bf16 mode): the epilogue staging and the

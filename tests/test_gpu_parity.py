@@ -433,7 +433,9 @@ def test_persistent_kernel_many_tiles_small_images(math, N, T, V, dev):
 @pytest.mark.parametrize("math,N,T,V", [("bf16x3", 5, 60, 22),     # large-tile persistent kernel (features path)
                                         ("bf16x3", 40, 180, 22),   # ... several tiles per workgroup
                                         ("bf16", 3, 33, 25),
-                                        ("bf16x3", 2, 40, 46),     # 128-pixel kernel (LMDHG graph), reads the x copy
+                                        ("bf16x3", 2, 40, 46),     # 128-pixel tile of the large-tile kernel (LMDHG graph)
+                                        ("bf16x3", 24, 60, 46),    # ... several of them per workgroup
+                                        ("bf16x3", 2, 2, 52),      # 128-pixel kernel KFb (only very wide, very short clips are left to it): reads the channel-major x copy
                                         ("f32", 3, 37, 22),        # fp32 matrix-core kernel
                                         ("f32", 2, 20, 46)])
 @pytest.mark.parametrize("out_bf16", [False, True])

@@ -843,3 +843,19 @@ def test_unit_agcn_backward_more_clips_than_workgroups(dev):
     parity_gate(y.detach(), yr.detach(), 1e-4, "training-mode forward, 300 clips")
     y.backward(G.to(dev))
     _compare_grads(_agcn_module_grads(gcn), ref, 1e-4)
+
+
+@pytest.mark.parametrize("V,T,N", [(22, 40, 3), (46, 20, 2)])
+def test_fused_stem_256_channels(V, T, N, dev):
+    """C = 256 (two 128-channel output groups, 16 input-channel chunks): fused bf16x3 stem against the fp64 oracle."""
+    from stgcn_amd import enable_stem_fusion
+    from oracle import stgcn_oracle as so
+    gcn, tcn, gp, tp, gen = _random_stem(V, None, 1500 + V, dev, c=256)
+    x = torch.randn(N, 3, T, V, generator=gen)
+    ref = so.stem_forward(x.double(), gp.to(torch.float64), tp.to(torch.float64))
+    with torch.no_grad():
+        two = tcn(gcn(x.to(dev)))
+        enable_stem_fusion(gcn, tcn)
+        fused = tcn(gcn(x.to(dev)))
+    parity_gate(two, ref, 1e-4, "two-stage, 256 channels")
+    parity_gate(fused, ref, 1e-4, "fused, 256 channels")

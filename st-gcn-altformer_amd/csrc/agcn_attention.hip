@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
     const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
     float *__restrict__ P, float *__restrict__ feat, int Cin, int T, int V, int inter_c, int S, int TC,
-    int Rp, int feat_slice_off, int xsc, int xsp, float *__restrict__ xcopy, unsigned long long *dbg) {
+    int Rp, int feat_slice_off, int sq_behind, int xsc, int xsp, float *__restrict__ xcopy, unsigned long long *dbg) {
     // x element (channel k, pixel p) of a clip sits at k*xsc + p*xsp: (T*V, 1) for (N,Cin,T,V), (1, Cin) for (N,T,V,Cin).
     // xcopy (optional): channel-major copy of x for kernels downstream that read it in that layout.
 #ifdef STGCN_ABLATION  // in-kernel cycle stamps (diagnostic builds only)
@@ -240,10 +240,13 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     // [hi f0-7][hi f8-15][lo f0-7][lo f8-15].
     if (feat == nullptr) return;
     // LDS operands of the feature loop, interleaved so that one ds_read_b128 brings what three ds_read_b32 did:
-    //   Sq[v][w] = (P_0, P_1, P_2, -)[v][w]  and  Xq[pixel] = (x_0, x_1, x_2, -), both in the dead Gram region
-    float4 *Sq = reinterpret_cast<float4 *>(U);
-    float4 *Xq = Sq + V * V;
-    const int TCF = (R * R - 4 * V * V) / (4 * V);   // (R*R = (3V+1)^2 > 9 V^2: always at least one frame)
+    //   Sq[v][w] = (P_0, P_1, P_2, -)[v][w]  and  Xq[pixel] = (x_0, x_1, x_2, -).  Xq lives in the dead Gram region;
+    //   Sq behind Gs and Sm when the LDS budget allows (sq_behind), else at the head of the Gram region as well
+    //   (wide frames: the 139 x 139 Gram of V = 46 leaves no room behind it).
+    const int sq_off = sq_behind ? ((R * R + S * V * V + 3) & ~3) : 0;
+    float4 *Sq = reinterpret_cast<float4 *>(U + sq_off);
+    float4 *Xq = reinterpret_cast<float4 *>(U) + (sq_behind ? 0 : V * V);
+    const int TCF = (R * R - (sq_behind ? 0 : 4 * V * V)) / (4 * V);   // (R*R = (3V+1)^2 > 9 V^2: at least one frame)
     __syncthreads();  // P complete in Sm
     for (int e = tid; e < V * V; e += NTH) Sq[e] = make_float4(Sm[e], Sm[V * V + e], Sm[2 * V * V + e], 0.f);
     // Each lane builds one 64-byte feature row; storing it directly is 16 B per lane at a 64-B stride (store-issue
@@ -380,16 +383,17 @@ __global__ __launch_bounds__(256) void attention_generic_kernel(
 // launch geometry of the folded kernel (shared by the capability query and the launcher)
 struct FoldedPlan {
     bool ok = false;
-    int maxit = 0, ts = 0, TC = 0, Rp = 0, slice_off = 0;
+    int maxit = 0, ts = 0, TC = 0, Rp = 0, slice_off = 0, sq_behind = 0;
     size_t lds = 0;
 };
 
-static FoldedPlan plan_folded_ts(int Cin, int T, int V, int inter_c, int S, bool with_features, int ts) {
+static FoldedPlan plan_folded_ts(int Cin, int T, int V, int inter_c, int S, bool with_features, int ts, bool sq_behind = false) {
     FoldedPlan pl;
     const int C1 = Cin + 1, R = Cin * V + 1;
     const int nTr = ceil_div(R, TM), nTc = ceil_div(R, TN);
     const int ntiles = nTr * nTc;
-    const size_t gs_floats = (size_t)R * R + (size_t)S * V * V;
+    const size_t gs_floats = (size_t)R * R + (size_t)S * V * V + (sq_behind ? (size_t)4 * V * V + 4 : 0);
+    pl.sq_behind = sq_behind ? 1 : 0;
     if (Cin > 4 || S * C1 * C1 > MS_FLOATS || ntiles > 8 * 256) return pl;
     if (with_features && (Cin != 3 || S != 3)) return pl;
     pl.maxit = ceil_div(ntiles, 256);
@@ -421,6 +425,10 @@ static FoldedPlan plan_folded(int Cin, int T, int V, int inter_c, int S, bool wi
     const int R = Cin * V + 1;
     const int maxit = ceil_div(ceil_div(R, TM) * ceil_div(R, TN), 256);
     if (maxit <= 4) {
+        if (with_features) {   // the interleaved P behind the Gram matrix: longer frame chunks in the feature pass
+            const FoldedPlan p4b = plan_folded_ts(Cin, T, V, inter_c, S, true, 4, true);
+            if (p4b.ok) return p4b;
+        }
         const FoldedPlan p4 = plan_folded_ts(Cin, T, V, inter_c, S, with_features, 4);
         if (p4.ok) return p4;
     }
@@ -448,7 +456,7 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
     do {                                                                                               \
         STGCN_HIP_CHECK(allow_lds((attention_folded_kernel<MI, TSL>), lds));                           \
         hipLaunchKernelGGL((attention_folded_kernel<MI, TSL>), dim3(N), dim3(256 * TSL), lds, st, x, A_eff, \
-                           Wa, ba, Wb, bb, P, feat, Cin, T, V, inter_c, S, TC, Rp, slice_off, xsc, xsp, xcopy, debug_buffer()); \
+                           Wa, ba, Wb, bb, P, feat, Cin, T, V, inter_c, S, TC, Rp, slice_off, pl.sq_behind, xsc, xsp, xcopy, debug_buffer()); \
     } while (0)
         if (pl.ts == 4) {
             if (pl.maxit <= 1) LAUNCH_FOLDED(1, 4);

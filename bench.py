@@ -156,14 +156,14 @@ def main():
     if args.layout == "ntvc":
         x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)   # (N,T,V,3) in memory, viewed (N,3,T,V)
         stgcn_amd.set_output_layout(tcn, "channels_last")
-    stats = None
+    stats, pending = None, None
 
     def step():
-        nonlocal stats
+        nonlocal stats, pending
         with torch.no_grad():
             out = tcn(gcn(x))
-        if world > 1:                                            # tiny, latency-bound; RCCL over xGMI
-            stats = sd.all_reduce_stats(sd.step_stats(out, n_local))
+        if world > 1:   # tiny, latency-bound; RCCL over xGMI on its own stream, beside the next step's kernels
+            stats, pending = sd.all_reduce_stats_async(sd.step_stats(out, n_local))
         return out
 
     def fence():
@@ -185,6 +185,8 @@ def main():
     kern_ms = timer.mean_ms("stem_tail")
     elapsed = sd.max_over_ranks(elapsed, dev)
     assert torch.isfinite(out).all()
+    if pending is not None:
+        pending.wait()
     if stats is not None:
         assert int(stats[0].item()) == n_local * world, "all-reduced clip count disagrees with the sharding"
 

@@ -37,7 +37,8 @@ def _worker(rank, world, port, n_total, q):
     x = torch.randn(n_total, 128, 6, 22, generator=gen)                 # same batch on every rank
     mine = sd.shard(x, rank, world)
     out = so.tcn_forward(mine, tp)
-    stats = sd.all_reduce_stats(sd.step_stats(out, mine.shape[0]))
+    stats, work = sd.all_reduce_stats_async(sd.step_stats(out, mine.shape[0]))   # what bench.py issues every step
+    work.wait()
     tmax = sd.max_over_ranks(0.1 * (rank + 1), torch.device("cpu"))
     sd.barrier()
     # numpy (pickled by value): torch tensors would travel as shared-memory handles that die with this process

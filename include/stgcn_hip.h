@@ -160,11 +160,14 @@ int stgcn_stem_forward_prepared(const float *x, const float *A_eff, const float 
  * batch over (N,T,V) and updates its running buffers in place exactly like torch (momentum, unbiased
  * variance); num_batches_tracked is the caller's to increment.  bn_* / dbn_* are the raw BatchNorm
  * tensors (weight, bias, running_mean, running_var), not folded scale/shift.  `ws` is caller workspace
- * of stgcn_*_train_ws_bytes bytes.  Forward only: no gradients are produced.
+ * of stgcn_*_train_ws_bytes bytes.
  *   stgcn_agcn_forward_train <- model/unit_agcn.py:73-93 with self.training (P_ws, y as in stgcn_agcn_forward)
  *   stgcn_tcn_forward_train  <- model/net.py:47-57 with self.training (dropout p = 0)
  */
-size_t stgcn_agcn_train_ws_bytes(int N, int Cout, int T, int V);
+/* materialise = 1: room for the two pre-BatchNorm branches (when save_zm/save_zd are wanted, or the shape is outside
+ * the stem class); 0: the stem class (C_in=3, 3 subsets, down branch) derives the batch statistics from the moments of its
+ * 12 per-pixel features and never writes the branches — scratch of a few hundred KB. */
+size_t stgcn_agcn_train_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets, int materialise);
 int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa, const float *ba,
                              const float *Wb, const float *bb, const float *Wd, const float *bd,
                              const float *Wdown, const float *bdown, const float *bn_weight,
@@ -174,23 +177,26 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
                              size_t ws_bytes, float *y, float *save_zm, float *save_zd, float *save_stats,
                              int N, int Cin, int Cout, int T, int V, int inter_c, int subsets,
                              void *stream);
-/* save_zm / save_zd (N,Cout,T,V): the two pre-BatchNorm branches (sum_s conv_d_s(x P_s), conv_down(x));
- * save_stats (4*Cout): batch mean, invstd of `bn`, then of the down BatchNorm.  Optional (NULL), for the
- * backward: */
-size_t stgcn_agcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets); /* 0: shape not covered */
+/* save_zm / save_zd (N,Cout,T,V): the two pre-BatchNorm branches (sum_s conv_d_s(x P_s), conv_down(x)) — asking for
+ * them selects the materialising path; save_stats (4*Cout): batch mean, invstd of `bn`, then of the down BatchNorm.
+ * All optional (NULL).  The backward takes zm / zd or recomputes them (NULL): */
+/* recompute = 1: zm / zd are not supplied (the forward ran the moments path); 0: they are.  Returns 0 for a shape that
+ * is not covered. */
+size_t stgcn_agcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets, int recompute);
 /* Gradients of every parameter of unit_agcn (model/unit_agcn.py:35-62) from dy (N,Cout,T,V) in training mode:
  * dWa/dWb (S,inter_c,Cin), dba/dbb (S,inter_c), dWd (S,Cout,Cin), dbd (S,Cout), dWdown (Cout,Cin), dbdown, the
- * two BatchNorms' dgamma/dbeta (main, then "dd" = down), dPA (S,V,V).  x is data: no dx.  Covers the stem's
- * shape class (Cin = 3, 3 subsets, Cout in {64,128,256}, down branch present); else STGCN_ERR_UNSUPPORTED. */
+ * two BatchNorms' dgamma/dbeta (main, then "dd" = down), dPA (S,V,V).  x is data: no dx.  zm / zd: the branches the
+ * forward saved, or both NULL to have them rebuilt here.  Covers the stem's shape class (Cin = 3, 3 subsets,
+ * Cout in {64,128,256}, down branch present); else STGCN_ERR_UNSUPPORTED. */
 int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *Wa, const float *ba,
-                              const float *Wb, const float *bb, const float *Wd, const float *P,
-                              const float *zm, const float *zd, const float *bn_weight,
-                              const float *bn_bias, const float *dbn_weight, const float *dbn_bias,
-                              const float *save_stats, const float *dy, float *dWa, float *dba, float *dWb,
-                              float *dbb, float *dWd, float *dbd, float *dWdown, float *dbdown,
-                              float *dgamma, float *dbeta, float *ddgamma, float *ddbeta, float *dPA,
-                              void *ws, size_t ws_bytes, int N, int Cin, int Cout, int T, int V,
-                              int inter_c, int subsets, void *stream);
+                              const float *Wb, const float *bb, const float *Wd, const float *bd,
+                              const float *Wdown, const float *bdown, const float *P, const float *zm,
+                              const float *zd, const float *bn_weight, const float *bn_bias,
+                              const float *dbn_weight, const float *dbn_bias, const float *save_stats,
+                              const float *dy, float *dWa, float *dba, float *dWb, float *dbb, float *dWd,
+                              float *dbd, float *dWdown, float *dbdown, float *dgamma, float *dbeta,
+                              float *ddgamma, float *ddbeta, float *dPA, void *ws, size_t ws_bytes, int N,
+                              int Cin, int Cout, int T, int V, int inter_c, int subsets, void *stream);
 size_t stgcn_tcn_train_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
 /* save_z (N,Cout,T_out,V), save_mean, save_invstd (Cout): optional outputs for the backward — the raw
  * convolution conv_t(x)+b and the batch statistics, torch's save_mean / save_invstd.  NULL: not kept. */

@@ -249,8 +249,11 @@ int stgcn_stem_forward_prepared(const float *x, const float *A_eff, const float 
 // workspace layout (agcn): [ones C][zeros C][scale/shift 4*C floats][sums 2 x 2C doubles][z_main N*C*T*V][z_down N*C*T*V]
 static size_t train_small_bytes(int C) { return align_up((size_t)C * 6 * sizeof(float) + (size_t)C * 4 * sizeof(double), 256); }
 
-size_t stgcn_agcn_train_ws_bytes(int N, int Cout, int T, int V) {
-    if (N <= 0 || Cout <= 0 || T <= 0 || V <= 0) return 0;
+// materialise != 0: room for the two pre-BatchNorm branches (needed when they are to be saved, or for shapes the
+// moments path does not cover); 0: the moments path's scratch only
+size_t stgcn_agcn_train_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets, int materialise) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || subsets <= 0) return 0;
+    if (!materialise && agcn_moments_supported(Cin, V, subsets)) return train_small_bytes(Cout) + agcn_moments_ws_bytes(N);
     return train_small_bytes(Cout) + (size_t)2 * N * Cout * T * V * sizeof(float);
 }
 
@@ -275,10 +278,19 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
         return fail(STGCN_ERR_ARG, "agcn_forward_train: identity residual needs Cin == Cout (got %d, %d)", Cin, Cout);
     int rc = stgcn_agcn_attention(x, A_eff, Wa, ba, Wb, bb, P_ws, N, Cin, T, V, inter_c, subsets, stream);
     if (rc != STGCN_OK) return rc;
-    if (ws_bytes < stgcn_agcn_train_ws_bytes(N, Cout, T, V))
+    const bool moments = has_down && !save_zm && !save_zd && agcn_moments_supported(Cin, V, subsets);
+    if (ws_bytes < stgcn_agcn_train_ws_bytes(N, Cin, Cout, T, V, subsets, moments ? 0 : 1))
         return fail(STGCN_ERR_WORKSPACE, "agcn_forward_train: workspace %zu B too small", ws_bytes);
     hipStream_t st = (hipStream_t)stream;
     float *ones = (float *)ws, *zeros = ones + Cout, *s1 = zeros + Cout, *t1 = s1 + Cout, *s2 = t1 + Cout, *t2 = s2 + Cout;
+    if (moments) {   // batch statistics from the moments of the 12 per-pixel features; the branches are never written
+        double *part = (double *)((char *)ws + train_small_bytes(Cout));
+        rc = launch_agcn_moments(x, P_ws, part, Wd, bd, Wdown, bdown, bn_weight, bn_bias, bn_running_mean, bn_running_var,
+                                 dbn_weight, dbn_bias, dbn_running_mean, dbn_running_var, momentum, eps, s1, t1, s2, t2,
+                                 save_stats, N, Cin, Cout, T, V, subsets, st);
+        if (rc != STGCN_OK) return rc;
+        return launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, s1, t1, s2, t2, y, N, Cin, Cout, T, V, subsets, 0, st);
+    }
     double *sums1 = (double *)(t2 + Cout), *sums2 = sums1 + 2 * Cout;
     float *zm = save_zm ? save_zm : (float *)((char *)ws + train_small_bytes(Cout));
     float *zd = save_zd ? save_zd : (float *)((char *)ws + train_small_bytes(Cout)) + (size_t)N * Cout * T * V;
@@ -312,44 +324,62 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
 }
 
 // ---- backward of the training-mode graph conv (stem shape class) --------------------------------------------------
-// workspace: [sums 3C dbl][coef_m 3C][coef_d 3C][scale_m, shift_m, scale_d, shift_d] | per-workgroup partials
+// workspace: [sums 3C dbl][coef_m 3C][coef_d 3C][scale_m, shift_m, scale_d, shift_d][ones, zeros] | per-workgroup partials
+//            | (recompute) the two pre-BatchNorm branches
 static size_t agcn_bwd_small_bytes(int Cout) {
-    return align_up((size_t)Cout * 3 * sizeof(double) + (size_t)Cout * 10 * sizeof(float), 256);
+    return align_up((size_t)Cout * 3 * sizeof(double) + (size_t)Cout * 12 * sizeof(float), 256);
 }
 
-size_t stgcn_agcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets) {
+size_t stgcn_agcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets, int recompute) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || subsets <= 0) return 0;
     const size_t part = agcn_bwd_part_bytes(N, Cin, Cout, T, V, subsets);
-    return part ? agcn_bwd_small_bytes(Cout) + part : 0;   // 0: shape not covered
+    if (!part) return 0;                                   // shape not covered
+    return agcn_bwd_small_bytes(Cout) + align_up(part, 256) + (recompute ? (size_t)2 * N * Cout * T * V * sizeof(float) : 0);
 }
 
 int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *Wa, const float *ba, const float *Wb,
-                              const float *bb, const float *Wd, const float *P, const float *zm, const float *zd,
-                              const float *bn_weight, const float *bn_bias, const float *dbn_weight,
-                              const float *dbn_bias, const float *save_stats, const float *dy, float *dWa, float *dba,
-                              float *dWb, float *dbb, float *dWd, float *dbd, float *dWdown, float *dbdown, float *dgamma,
-                              float *dbeta, float *ddgamma, float *ddbeta, float *dPA, void *ws, size_t ws_bytes, int N,
-                              int Cin, int Cout, int T, int V, int inter_c, int subsets, void *stream) {
+                              const float *bb, const float *Wd, const float *bd, const float *Wdown, const float *bdown,
+                              const float *P, const float *zm, const float *zd, const float *bn_weight,
+                              const float *bn_bias, const float *dbn_weight, const float *dbn_bias,
+                              const float *save_stats, const float *dy, float *dWa, float *dba, float *dWb, float *dbb,
+                              float *dWd, float *dbd, float *dWdown, float *dbdown, float *dgamma, float *dbeta,
+                              float *ddgamma, float *ddbeta, float *dPA, void *ws, size_t ws_bytes, int N, int Cin, int Cout,
+                              int T, int V, int inter_c, int subsets, void *stream) {
     REQUIRE_PTR(x); REQUIRE_PTR(A_eff); REQUIRE_PTR(Wa); REQUIRE_PTR(ba); REQUIRE_PTR(Wb); REQUIRE_PTR(bb); REQUIRE_PTR(Wd);
-    REQUIRE_PTR(P); REQUIRE_PTR(zm); REQUIRE_PTR(zd); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias); REQUIRE_PTR(dbn_weight);
-    REQUIRE_PTR(dbn_bias); REQUIRE_PTR(save_stats); REQUIRE_PTR(dy); REQUIRE_PTR(dWa); REQUIRE_PTR(dba); REQUIRE_PTR(dWb);
-    REQUIRE_PTR(dbb); REQUIRE_PTR(dWd); REQUIRE_PTR(dbd); REQUIRE_PTR(dWdown); REQUIRE_PTR(dbdown); REQUIRE_PTR(dgamma);
-    REQUIRE_PTR(dbeta); REQUIRE_PTR(ddgamma); REQUIRE_PTR(ddbeta); REQUIRE_PTR(dPA); REQUIRE_PTR(ws);
+    REQUIRE_PTR(bd); REQUIRE_PTR(Wdown); REQUIRE_PTR(bdown); REQUIRE_PTR(P); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias);
+    REQUIRE_PTR(dbn_weight); REQUIRE_PTR(dbn_bias); REQUIRE_PTR(save_stats); REQUIRE_PTR(dy); REQUIRE_PTR(dWa); REQUIRE_PTR(dba);
+    REQUIRE_PTR(dWb); REQUIRE_PTR(dbb); REQUIRE_PTR(dWd); REQUIRE_PTR(dbd); REQUIRE_PTR(dWdown); REQUIRE_PTR(dbdown);
+    REQUIRE_PTR(dgamma); REQUIRE_PTR(dbeta); REQUIRE_PTR(ddgamma); REQUIRE_PTR(ddbeta); REQUIRE_PTR(dPA); REQUIRE_PTR(ws);
     REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(Cout); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(inter_c); REQUIRE_POS(subsets);
+    if ((zm == nullptr) != (zd == nullptr)) return fail(STGCN_ERR_ARG, "agcn_backward: give both saved branches or neither");
     if (!agcn_bwd_supported(N, Cin, Cout, T, V, subsets))
         return fail(STGCN_ERR_UNSUPPORTED,
                     "agcn_backward: covers Cin=3, 3 subsets, Cout in {64,128,256}, a down branch (got Cin=%d S=%d Cout=%d V=%d)",
                     Cin, subsets, Cout, V);
-    const size_t need = stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, subsets);
+    const bool recompute = zm == nullptr;
+    const size_t need = stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, subsets, recompute ? 1 : 0);
     if (ws_bytes < need) return fail(STGCN_ERR_WORKSPACE, "agcn_backward: workspace %zu B < %zu B", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     const size_t plane = (size_t)T * V;
     double *sums = (double *)ws;
     float *coefm = (float *)(sums + 3 * Cout), *coefd = coefm + 3 * Cout, *sm_ = coefd + 3 * Cout, *tm_ = sm_ + Cout,
-          *sd_ = tm_ + Cout, *td_ = sd_ + Cout;
+          *sd_ = tm_ + Cout, *td_ = sd_ + Cout, *ones = td_ + Cout, *zeros = ones + Cout;
     float *part = (float *)((char *)ws + agcn_bwd_small_bytes(Cout));
+    int rc;
+    if (recompute) {   // the forward kept no branches (moments path): rebuild them with the raw-mode expansion kernel
+        float *zmw = (float *)((char *)part + align_up(agcn_bwd_part_bytes(N, Cin, Cout, T, V, subsets), 256));
+        float *zdw = zmw + (size_t)N * Cout * plane;
+        hipLaunchKernelGGL(fill_ones_zeros_kernel, dim3(ceil_div(Cout, 256)), dim3(256), 0, st, ones, zeros, Cout);
+        STGCN_LAUNCH_CHECK("fill_ones_zeros_kernel");
+        rc = launch_agcn_expand(x, P, Wd, bd, Wdown, bdown, ones, zeros, zeros, zeros, zmw, N, Cin, Cout, T, V, subsets, 1 | 2, st);
+        if (rc != STGCN_OK) return rc;
+        rc = launch_agcn_expand(x, P, Wd, bd, Wdown, bdown, zeros, zeros, ones, zeros, zdw, N, Cin, Cout, T, V, subsets, 1, st);
+        if (rc != STGCN_OK) return rc;
+        zm = zmw;
+        zd = zdw;
+    }
     const float *mean_m = save_stats, *inv_m = save_stats + Cout, *mean_d = save_stats + 2 * Cout, *inv_d = save_stats + 3 * Cout;
-    int rc = launch_bn_scale_shift(bn_weight, bn_bias, mean_m, inv_m, sm_, tm_, Cout, st);
+    rc = launch_bn_scale_shift(bn_weight, bn_bias, mean_m, inv_m, sm_, tm_, Cout, st);
     if (rc != STGCN_OK) return rc;
     rc = launch_bn_scale_shift(dbn_weight, dbn_bias, mean_d, inv_d, sd_, td_, Cout, st);
     if (rc != STGCN_OK) return rc;

@@ -161,6 +161,15 @@ size_t tcn_wgrad_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int str
 int launch_tcn_wgrad(const float *dz, const float *x, float *dW, float *part, int N, int Cin, int Cout, int T, int V, int K,
                      int stride, int Tout, unsigned flags, hipStream_t st);
 
+// training-mode graph conv without materialised branches (agcn_train.hip)
+bool agcn_moments_supported(int Cin, int V, int S);
+size_t agcn_moments_ws_bytes(int N);
+int launch_agcn_moments(const float *x, const float *P, double *part, const float *Wd, const float *bd, const float *Wdown,
+                        const float *bdown, const float *bn_w, const float *bn_b, float *bn_rm, float *bn_rv,
+                        const float *dbn_w, const float *dbn_b, float *dbn_rm, float *dbn_rv, float momentum, float eps,
+                        float *s_m, float *t_m, float *s_d, float *t_d, float *save_stats, int N, int Cin, int Cout, int T,
+                        int V, int S, hipStream_t st);
+
 // backward of the training-mode graph conv (agcn_backward.hip)
 bool agcn_bwd_supported(int N, int Cin, int Cout, int T, int V, int S);
 size_t agcn_bwd_part_bytes(int N, int Cin, int Cout, int T, int V, int S);

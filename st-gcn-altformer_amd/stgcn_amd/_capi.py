@@ -50,10 +50,10 @@ PROTOTYPES = {
     "stgcn_stem_tail_prepared": (c_int, [_P] * 2 + [c_size_t] + [_P] * 3 + [c_int] * 7 + [c_uint, _P]),
     "stgcn_stem_forward_prepared": (c_int, [_P] * 9 + [c_size_t] + [_P] + [c_int] * 8 + [c_uint, _P]),
     "stgcn_step_stats": (c_int, [_P, c_int, _P, c_int, c_int, c_long, c_float, _P]),
-    "stgcn_agcn_train_ws_bytes": (c_size_t, [c_int] * 4),
+    "stgcn_agcn_train_ws_bytes": (c_size_t, [c_int] * 7),
     "stgcn_agcn_forward_train": (c_int, [_P] * 18 + [c_float, c_float, _P, _P, c_size_t] + [_P] * 4 + [c_int] * 7 + [_P]),
-    "stgcn_agcn_backward_ws_bytes": (c_size_t, [c_int] * 6),
-    "stgcn_agcn_backward_train": (c_int, [_P] * 29 + [_P, c_size_t] + [c_int] * 7 + [_P]),
+    "stgcn_agcn_backward_ws_bytes": (c_size_t, [c_int] * 7),
+    "stgcn_agcn_backward_train": (c_int, [_P] * 32 + [_P, c_size_t] + [c_int] * 7 + [_P]),
     "stgcn_tcn_train_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
     "stgcn_tcn_forward_train": (c_int, [_P] * 7 + [c_float, c_float, _P, c_size_t] + [_P] * 4 + [c_int] * 7 + [c_uint, _P]),
     "stgcn_tcn_backward_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),

@@ -227,19 +227,21 @@ def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_
                        save=False):
     """Training-mode forward of unit_agcn (batch-statistics BatchNorm; running buffers of `bn` / `down_bn` are
     updated in place like torch does).  bn / down_bn: (weight, bias, running_mean, running_var) tensors.
-    Returns (y, P); with ``save=True`` (y, P, zm, zd, stats) — the pre-BatchNorm branches and the batch
-    mean / invstd of both BatchNorms (4*Cout), which the backward reads."""
+    Returns (y, P); with ``save`` (y, P, zm, zd, stats): stats = batch mean / invstd of both BatchNorms (4*Cout);
+    zm, zd = the pre-BatchNorm branches, kept only with ``save="branches"`` (else None: the stem shape class then runs
+    the moments path, which never writes them, and the backward recomputes what it needs)."""
     dev = x.device
     N, Cin, T, V = x.shape
     S, inter_c, _ = Wa.shape
     Cout = Wd.shape[1]
     y = torch.empty(N, Cout, T, V, device=dev, dtype=torch.float32)
     P = torch.empty(N, S, V, V, device=dev, dtype=torch.float32)
-    nbytes = _capi.lib().stgcn_agcn_train_ws_bytes(N, Cout, T, V)
+    branches = save == "branches"            # keep zm / zd (the materialising path); save=True keeps the statistics only
+    nbytes = _capi.lib().stgcn_agcn_train_ws_bytes(N, Cin, Cout, T, V, S, 1 if (branches or down_bn is None) else 0)
     ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
     d = down_bn if down_bn is not None else (None, None, None, None)
-    zm = torch.empty_like(y) if save else None
-    zd = torch.empty_like(y) if save else None
+    zm = torch.empty_like(y) if branches else None
+    zd = torch.empty_like(y) if branches else None
     stats = torch.empty(4 * Cout, device=dev, dtype=torch.float32) if save else None
     with torch.cuda.device(dev):
         _capi.call("stgcn_agcn_forward_train", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev),
@@ -254,17 +256,19 @@ def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_
 
 
 def agcn_backward_supported(N, Cin, Cout, T, V, S) -> bool:
-    return _capi.lib().stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, S) > 0
+    return _capi.lib().stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, S, 1) > 0
 
 
-def agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, P, zm, zd, bn_weight, bn_bias, dbn_weight, dbn_bias, stats, dy):
-    """Parameter gradients of the training-mode unit_agcn forward (x is data: no dx).  Returns a dict keyed
-    dWa, dba, dWb, dbb, dWd, dbd, dWdown, dbdown, dgamma, dbeta, ddgamma, ddbeta, dPA."""
+def agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, zm, zd, bn_weight, bn_bias, dbn_weight,
+                        dbn_bias, stats, dy):
+    """Parameter gradients of the training-mode unit_agcn forward (x is data: no dx).  zm / zd: the saved pre-BatchNorm
+    branches, or None to have them rebuilt in the call's workspace.  Returns a dict keyed dWa, dba, dWb, dbb, dWd, dbd,
+    dWdown, dbdown, dgamma, dbeta, ddgamma, ddbeta, dPA."""
     dev = x.device
     N, Cin, T, V = x.shape
     S, inter_c, _ = Wa.shape
     Cout = Wd.shape[1]
-    nbytes = _capi.lib().stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, S)
+    nbytes = _capi.lib().stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, S, 1 if zm is None else 0)
     if nbytes == 0:
         raise NotImplementedError(f"unit_agcn backward: shape Cin={Cin} S={S} Cout={Cout} V={V} is not covered by the HIP path")
     ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
@@ -275,6 +279,7 @@ def agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, P, zm, zd, bn_weight, bn_b
     with torch.cuda.device(dev):
         _capi.call("stgcn_agcn_backward_train", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev), _dev_ptr(Wa, "Wa", dev),
                    _dev_ptr(ba, "ba", dev), _dev_ptr(Wb, "Wb", dev), _dev_ptr(bb, "bb", dev), _dev_ptr(Wd, "Wd", dev),
+                   _dev_ptr(bd, "bd", dev), _dev_ptr(Wdown, "Wdown", dev), _dev_ptr(bdown, "bdown", dev),
                    _dev_ptr(P, "P", dev), _dev_ptr(zm, "zm", dev), _dev_ptr(zd, "zd", dev),
                    _dev_ptr(bn_weight, "bn_weight", dev), _dev_ptr(bn_bias, "bn_bias", dev),
                    _dev_ptr(dbn_weight, "dbn_weight", dev), _dev_ptr(dbn_bias, "dbn_bias", dev),

@@ -99,15 +99,20 @@ class _AgcnTrainFn(torch.autograd.Function):
             x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"], st["bdown"],
             (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var),
             (d.weight.detach(), d.bias.detach(), d.running_mean, d.running_var), bn.momentum, bn.eps, save=True)
-        ctx.save_for_backward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], P, zm, zd,
-                              bn.weight.detach(), bn.bias.detach(), d.weight.detach(), d.bias.detach(), stats)
+        # (zm, zd are None: the stem shape class derives its BatchNorm statistics from feature moments and writes
+        #  neither branch; the backward rebuilds them in its own workspace — nothing full-size is kept in between)
+        ctx.save_for_backward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"],
+                              st["bdown"], P, bn.weight.detach(), bn.bias.detach(), d.weight.detach(), d.bias.detach(),
+                              stats)
         ctx.S = mod.num_subset
         mod.last_attention = P
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        g = F.agcn_backward_train(*ctx.saved_tensors, dy.contiguous())
+        x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, bnw, bnb, dbnw, dbnb, stats = ctx.saved_tensors
+        g = F.agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, None, None, bnw, bnb, dbnw, dbnb, stats,
+                                  dy.contiguous())
         S = ctx.S
         out = [g["dPA"]]
         for w, b in (("dWa", "dba"), ("dWb", "dbb"), ("dWd", "dbd")):

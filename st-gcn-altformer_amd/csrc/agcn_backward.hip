@@ -279,7 +279,8 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
     }
 }
 
-// Sums the per-workgroup partials in a fixed order: one thread per output element.
+// Sums the per-workgroup partials in a fixed order.  Workgroup = 32 output elements x 8 groups of partials: thread
+// (e = tid & 31, g = tid >> 5) adds partials g, g+8, ...; the 8 sub-sums of an element are then added in order g = 0..7.
 //   out_w [Cout][WCOLS] -> dWd (S,Cout,CIN), dbd (S,Cout), dWdown (Cout,CIN), dbdown (Cout);  dPA;  dM -> dm_out
 template <int CIN, int S>
 __global__ __launch_bounds__(256) void agcn_bwd_reduce_kernel(
@@ -288,24 +289,33 @@ __global__ __launch_bounds__(256) void agcn_bwd_reduce_kernel(
     float *__restrict__ dPA, float *__restrict__ dm_out, int Cout, int V) {
     constexpr int SC = S * CIN, C1 = CIN + 1, WCOLS = SC + 1 + CIN + 1, MAINF = SC + 1;
     const int nw = Cout * WCOLS, npa = S * V * V, nm = S * C1 * C1;
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float sub[8][32];
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    const float *src = nullptr;
+    size_t stride = 0;
+    int i = 0;
+    if (e < nw) { src = part_w; stride = nw; i = e; }
+    else if (e < nw + npa) { src = part_pa; stride = npa; i = e - nw; }
+    else if (e < nw + npa + nm) { src = part_m; stride = nm; i = e - nw - npa; }
+    float a = 0.f;
+    if (src != nullptr)
+        for (int p = grp; p < parts; p += 8) a += src[(size_t)p * stride + i];
+    sub[grp][el] = a;
+    __syncthreads();
+    if (grp != 0 || src == nullptr) return;
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += sub[g][el];
     if (e < nw) {
-        float s = 0.f;
-        for (int p = 0; p < parts; ++p) s += part_w[(size_t)p * nw + e];
         const int o = e / WCOLS, c = e - o * WCOLS;
         if (c < SC) dWd[((size_t)(c / CIN) * Cout + o) * CIN + (c % CIN)] = s;
         else if (c == SC) { for (int q = 0; q < S; ++q) dbd[q * Cout + o] = s; }   // every bd_s adds straight into zm
         else if (c < MAINF + CIN) dWdown[o * CIN + (c - MAINF)] = s;
         else dbdown[o] = s;
     } else if (e < nw + npa) {
-        const int i = e - nw;
-        float s = 0.f;
-        for (int p = 0; p < parts; ++p) s += part_pa[(size_t)p * npa + i];
         dPA[i] = s;
-    } else if (e < nw + npa + nm) {
-        const int i = e - nw - npa;
-        float s = 0.f;
-        for (int p = 0; p < parts; ++p) s += part_m[(size_t)p * nm + i];
+    } else {
         dm_out[i] = s;
     }
 }
@@ -394,7 +404,7 @@ int launch_agcn_bwd(const float *x, const float *P, const float *A_eff, const fl
 #undef LAUNCH_BWD
     STGCN_LAUNCH_CHECK("agcn_bwd_kernel");
     const int total = Cout * WCOLS + S * V * V + S * C1 * C1;
-    hipLaunchKernelGGL((agcn_bwd_reduce_kernel<3, 3>), dim3(ceil_div(total, 256)), dim3(256), 0, st, part_w, part_pa, part_m,
+    hipLaunchKernelGGL((agcn_bwd_reduce_kernel<3, 3>), dim3(ceil_div(total, 32)), dim3(256), 0, st, part_w, part_pa, part_m,
                        pl.grid, dWd, dbd, dWdown, dbdown, dPA, dm_sum, Cout, V);
     STGCN_LAUNCH_CHECK("agcn_bwd_reduce_kernel");
     hipLaunchKernelGGL((agcn_bwd_embed_kernel<3, 3>), dim3(1), dim3(256), 0, st, dm_sum, Wa, ba, Wb, bb, dWa, dba, dWb, dbb,

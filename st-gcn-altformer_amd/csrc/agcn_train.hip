@@ -111,12 +111,17 @@ __global__ __launch_bounds__(256) void agcn_moments_finalize_kernel(
     float *__restrict__ save_stats /* 4*Cout or NULL */, int Cout) {
     constexpr int SC = S * CIN;
     __shared__ double mom[NMOM];
+    __shared__ double sub[4][64];
     const int tid = threadIdx.x;
-    if (tid < NMOM) {
+    {   // 4 groups of partials per moment, then a fixed-order sum of the 4 sub-sums
+        const int i = tid & 63, grp = tid >> 6;
         double s = 0.0;
-        for (int p = 0; p < parts; ++p) s += part[(size_t)p * NMOM + tid];
-        mom[tid] = s / count;
+        if (i < NMOM)
+            for (int p = grp; p < parts; p += 4) s += part[(size_t)p * NMOM + i];
+        sub[grp][i] = s;
     }
+    __syncthreads();
+    if (tid < NMOM) mom[tid] = (((sub[0][tid] + sub[1][tid]) + sub[2][tid]) + sub[3][tid]) / count;
     __syncthreads();
     const double *mu = mom, *muu = mom + SC, *mx = mom + SC + 45, *mxx = mom + SC + 45 + CIN;
     for (int o = tid; o < Cout; o += 256) {

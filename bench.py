@@ -6,15 +6,32 @@
         --master-port P bench.py --gpus N --steps K --warmup W      # N>1, launched by the driver
 
 A step = one pass of the stem (attention kernel + fused graph-conv/temporal-conv kernel, called
-through the drop-in nn.Modules) over one batch of synthetic clips already resident in HBM.  Clips are
-independent, so ranks own disjoint shards (weak scaling: --clips-per-gpu per rank) and the data path
-has no collective; with N>1 each step ends with one tiny RCCL all-reduce of (clip count, output
-checksum sample) — the DP form of the reference's accuracy reduction (train_sttran.py:105-109).
+through the drop-in nn.Modules) over this rank's synthetic clips, already resident in HBM.  Clips are
+independent, so ranks own disjoint shards and the data path has no collective; with N>1 each step ends
+with one tiny RCCL all-reduce of (clip count, output checksum sample) — the DP form of the reference's
+accuracy reduction (train_sttran.py:105-109).
 
-Rank 0 prints ONE JSON line: clips/s (whole job), ms/step, `roofline` for the dominant kernel
-(HIP-event timed on the launching stream) and `cpu_baseline` (the CPU oracle on the host cores).
+Two workloads:
+  default                weak scaling, --clips-per-gpu (256 = BASELINE configs[1]) clips on every rank;
+  --global-clips 8192    BASELINE configs[4]: ONE batch of 8192 clips sharded over the ranks
+                         (stgcn_amd.dist.shard_bounds), strong scaling; a rank walks its shard in sub-batches of
+                         at most --sub-batch clips (512: features + output of one sub-batch stay inside the
+                         256 MB Infinity Cache), so a step is ceil(shard / sub-batch) stem passes.
+
+Rank 0 prints ONE JSON line.  Besides the contract's fields:
+  roofline      the dominant kernel, HIP-event timed on the launching stream over the timed region;
+                `traffic` (HBM bytes per launch from the committed rocprofv3 PMC summary) is quoted only when
+                the kernels' sources are byte-identical to the ones that profile was taken on (`traffic_source`);
+  steady_state  a second, longer timed block in the same process (the driver's 20 steps run while the
+                clocks still ramp after idle; this block shows where the figure settles);
+  alt           a short block with the exact-fp32 arithmetic (STGCN_MATH_F32) and its own roofline;
+  cpu_baseline  the stem on torch's library CPU ops (oneDNN conv etc., oracle/stgcn_cpu_ops.py: the op mix the
+                reference itself runs), rank 0 at N=1 only; `cpu_oracle` = the einsum oracle timed the same way.
+Order inside the process: headline block, steady-state block, fp32 block, CPU legs (the GPU is never left
+idle behind a CPU leg before a GPU measurement).
 """
 import argparse
+import hashlib
 import json
 import os
 import statistics
@@ -32,6 +49,8 @@ import torch         # noqa: E402
 
 HBM_PEAK = 8.0e12                       # B/s, MI355X spec (MI355X_MICROARCH.md); measured copy ~6.29e12
 MFMA_PEAK = {"f32": 157.3e12, "f32_valu": 157.3e12, "bf16": 2.5e15, "bf16x3": 2.5e15}   # dense FLOP/s
+DTYPE_NAME = {"f32": "f32", "f32_valu": "f32", "bf16": "bf16",
+              "bf16x3": "bf16x3 (fp32 operands split hi+lo bf16, 3 MFMAs, fp32 accumulate)"}
 
 
 def build_stem(V, graph_name, math, seed=1234):
@@ -64,58 +83,90 @@ def synthetic_clips(n, T, V, seed):
     return skel.permute(0, 3, 1, 2).contiguous()                  # ST_GCN_AltFormer.py:64-68
 
 
-def cpu_baseline(gcn, tcn, T, V, clips, reps):
-    """The CPU oracle (torch CPU fp32 restatement) on this host's cores; bounded sample."""
-    from oracle import stgcn_oracle as so
-    gp = so.agcn_params_from_state({k: v.cpu() for k, v in gcn.state_dict().items()}, gcn.A.cpu())
-    tp = so.tcn_params_from_state({k: v.cpu() for k, v in tcn.state_dict().items()})
-    x = synthetic_clips(clips, T, V, 0)
+def _host_cores():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("STGCN_CPU_THREADS", "16"))))   # the GPU box's CPU share is 16
-    torch.set_num_threads(cores)
-    times = []
-    with torch.no_grad():
-        for i in range(2 + reps):
-            t0 = time.perf_counter()
-            so.stem_forward(x, gp, tp)
-            dt = time.perf_counter() - t0
-            if i >= 2:
-                times.append(dt)
-    med = statistics.median(times)
-    return {"value": round(clips / med, 2), "unit": "clips/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{clips} clips (T={T},V={V}) x median of {reps} after 2 warm-ups, {med * 1e3:.0f} ms/pass, "
-                      f"oracle/stgcn_oracle.py fp32 torch-CPU"}
+    return max(1, min(cores, int(os.environ.get("STGCN_CPU_THREADS", "16"))))   # the GPU box's CPU share is 16
 
 
-def profiled_traffic(kernel_prefix, default_config):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/*_counters.json,
-    FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes; tools/collect_profiles.sh) — only for the default
-    workload those profiles were taken on; None otherwise."""
-    if not default_config:
-        return None
+def cpu_legs(gcn_state, tcn_state, A, T, V, clips, reps):
+    """Bounded CPU timings on this host's cores: (library-op baseline, einsum oracle).  Both compute the same
+    stem (tests/test_oracle_golden.py::test_cpu_ops_*); the first is what the reference's own CPU forward costs."""
+    from oracle import stgcn_cpu_ops as co
+    from oracle import stgcn_oracle as so
+    gp = so.agcn_params_from_state(gcn_state, A)
+    tp = so.tcn_params_from_state(tcn_state)
+    x = synthetic_clips(clips, T, V, 0)
+    torch.set_num_threads(_host_cores())
+
+    def timed(fn, what):
+        times = []
+        with torch.no_grad():
+            for i in range(2 + reps):
+                t0 = time.perf_counter()
+                fn(x, gp, tp)
+                dt = time.perf_counter() - t0
+                if i >= 2:
+                    times.append(dt)
+        med = statistics.median(times)
+        return {"value": round(clips / med, 2), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{clips} clips (T={T},V={V}) x median of {reps} after 2 warm-ups, {med * 1e3:.0f} ms/pass, {what}"}
+
+    base = timed(co.stem_forward_ops, "oracle/stgcn_cpu_ops.py: fp32 torch-CPU library ops (F.conv2d / F.batch_norm / matmul, "
+                                      "the reference's op mix)")
+    orc = timed(so.stem_forward, "oracle/stgcn_oracle.py: fp32 torch-CPU einsum restatement (the parity checker)")
+    return base, orc
+
+
+def csrc_digest():
+    """Content hash of every kernel source + the ABI header: identifies the binary a profile belongs to (the GPU box
+    has no .git).  tools/summarize_profiles.py stores the same digest next to the counters it condenses."""
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, "st-gcn-altformer_amd", "csrc")
+    files = sorted(os.path.join(cs, f) for f in os.listdir(cs) if f.endswith((".hip", ".h")))
+    for path in files + [os.path.join(ROOT, "include", "stgcn_hip.h")]:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic(kernel_prefix, workload_key):
+    """(bytes per launch, source) of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/*_counters.json: FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes, tools/collect_profiles.sh) —
+    only when that profile was taken on this workload AND on these kernel sources; (None, reason) otherwise."""
     import glob
+    digest = csrc_digest()
+    reason = "no PMC summary under profiles/"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")), reverse=True):
         try:
-            for name, m in json.load(open(path)).items():
-                if name.startswith(kernel_prefix) and "hbm_traffic_bytes_per_launch" in m:
-                    return int(m["hbm_traffic_bytes_per_launch"])
+            doc = json.load(open(path))
         except (OSError, ValueError):
             continue
-    return None
+        meta = doc.get("_meta", {})
+        if meta.get("workload") != workload_key:
+            reason = f"newest PMC summaries are of another workload ({meta.get('workload')!r})"
+            continue
+        if meta.get("csrc_digest") != digest:
+            reason = (f"{os.path.basename(path)} was taken on csrc {meta.get('csrc_digest')}, this binary is {digest}: "
+                      "not quoted")
+            continue
+        for name, m in doc.items():
+            if name.startswith(kernel_prefix) and "hbm_traffic_bytes_per_launch" in m:
+                return int(m["hbm_traffic_bytes_per_launch"]), f"profiles/{os.path.basename(path)}@csrc:{digest}"
+    return None, reason
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200,
-                    help="timed steps; the default is long enough (~0.2 s) for the GPU clocks to settle: 20-step runs measure the "
-                         "ramp after idle and read ~12 %% low (DESIGN.md section 5)")
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--clips-per-gpu", type=int, default=256, help="256 = BASELINE configs[1]; 1024 = configs[4] at 8 GPUs")
+    ap.add_argument("--clips-per-gpu", type=int, default=256, help="weak-scaling shard size; 256 = BASELINE configs[1]")
+    ap.add_argument("--global-clips", type=int, default=0,
+                    help="strong scaling: ONE batch of this many clips sharded over the ranks (8192 = BASELINE configs[4])")
+    ap.add_argument("--sub-batch", type=int, default=512, help="largest number of clips per stem pass in --global-clips mode")
     ap.add_argument("--frames", type=int, default=180)
     ap.add_argument("--graph", choices=["SHRE", "LMDHG"], default="SHRE")
     ap.add_argument("--math", choices=["f32", "bf16x3", "bf16", "f32_valu"], default=os.environ.get("STGCN_MATH", "bf16x3"))
@@ -123,9 +174,15 @@ def main():
     ap.add_argument("--layout", choices=["nctv", "ntvc"], default="nctv",
                     help="nctv = the reference's call (contiguous (N,3,T,V) in, (N,C,T,V) out; the headline); ntvc = SURVEY "
                          "§8(f)-1 layout fusion: the loader's (N,T,V,3) batch read in place, (N,T,V,C) written")
+    ap.add_argument("--steady-steps", type=int, default=300, help="length of the second timed block (0 = skip)")
+    ap.add_argument("--alt-steps", type=int, default=40, help="timed steps of the exact-fp32 block (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="headline block only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=32)
     args = ap.parse_args()
+    if args.no_extras:
+        args.steady_steps = args.alt_steps = 0
+        args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -144,24 +201,46 @@ def main():
     sd.init(backend, dev)                                        # no-op at world 1
 
     T, V = args.frames, 22 if args.graph == "SHRE" else 46
-    n_local = args.clips_per_gpu
+    strong = args.global_clips > 0
+    if strong:
+        lo, hi = sd.shard_bounds(args.global_clips, rank, world)
+        n_local, n_global = hi - lo, args.global_clips
+        seed0 = 1000
+    else:
+        n_local, n_global = args.clips_per_gpu, args.clips_per_gpu * world
+        lo, seed0 = 0, rank
     gcn, tcn = build_stem(V, args.graph, args.math)
-    cpu = None
+    cpu_state = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(gcn, tcn, T, V, args.cpu_clips, 5)
+        cpu_state = ({k: v.clone() for k, v in gcn.state_dict().items()},
+                     {k: v.clone() for k, v in tcn.state_dict().items()}, gcn.A.clone())
     gcn, tcn = gcn.to(dev).eval(), tcn.to(dev).eval()
     if not args.no_fuse:
         stgcn_amd.enable_stem_fusion(gcn, tcn)
-    x = synthetic_clips(n_local, T, V, seed=rank).to(dev)        # this rank's shard, resident in HBM before timing
+
+    # this rank's clips, resident in HBM before any timing, cut into sub-batches (one, in the default workload)
+    sub = min(args.sub_batch, n_local) if strong else n_local
+    shard = []
+    for s in range(0, n_local, sub):
+        n = min(sub, n_local - s)
+        if strong:   # seeded by the sub-batch's position in the global batch
+            xs = synthetic_clips(n, T, V, seed=seed0 + (lo + s)).to(dev)
+        else:
+            xs = synthetic_clips(n, T, V, seed=seed0).to(dev)
+        if args.layout == "ntvc":
+            xs = xs.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)   # (N,T,V,3) in memory, viewed (N,3,T,V)
+        shard.append(xs)
     if args.layout == "ntvc":
-        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)   # (N,T,V,3) in memory, viewed (N,3,T,V)
         stgcn_amd.set_output_layout(tcn, "channels_last")
+    launches_per_step = len(shard)
     stats, pending = None, None
 
     def step():
         nonlocal stats, pending
+        out = None
         with torch.no_grad():
-            out = tcn(gcn(x))
+            for xs in shard:
+                out = tcn(gcn(xs))
         if world > 1:   # tiny, latency-bound; RCCL over xGMI on its own stream, beside the next step's kernels
             stats, pending = sd.all_reduce_stats_async(sd.step_stats(out, n_local))
         return out
@@ -171,66 +250,116 @@ def main():
         sd.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        out = step()
-    timer = F.KernelTimer()
-    F.kernel_timer = timer
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    F.kernel_timer = None
-    kern_ms = timer.mean_ms("stem_tail")
-    elapsed = sd.max_over_ranks(elapsed, dev)
+    def timed_block(steps, warm):
+        """`warm` untimed steps, then exactly `steps` steps between two fences; (seconds max over ranks, kernel ms)."""
+        out = None
+        for _ in range(warm):
+            out = step()
+        timer = F.KernelTimer()
+        F.kernel_timer = timer
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        fence()
+        dt = time.perf_counter() - t0
+        F.kernel_timer = None
+        return sd.max_over_ranks(dt, dev), timer.mean_ms("stem_tail"), timer.count("stem_tail"), out
+
+    elapsed, kern_ms, n_launch, out = timed_block(args.steps, args.warmup)
     assert torch.isfinite(out).all()
     if pending is not None:
         pending.wait()
     if stats is not None:
-        assert int(stats[0].item()) == n_local * world, "all-reduced clip count disagrees with the sharding"
+        assert int(round(stats[0].item())) == n_global, "all-reduced clip count disagrees with the sharding"
 
+    bytes_clip = 4 * T * V * (3 + 128)                       # fused stem: x in + activation out (SURVEY §8d)
+    flops_clip = 2 * 128 * 128 * 9 * T * V + 2 * T * V * (3 * 3 * V + 128 * 13)   # temporal conv + graph conv
+    clips_per_launch = n_local / launches_per_step
+
+    def kernel_name(math):
+        from stgcn_amd import _capi
+        v4 = math in ("bf16x3", "bf16") and bool(_capi.lib().stgcn_stem_features_used(3, 128, T, V, 9, 3, F._flags(
+            {"bf16x3": F.MATH_BF16X3, "bf16": F.MATH_BF16}.get(math, 0), False)))
+        if args.no_fuse:
+            return "tcn_bf16_v4_kernel" if math in ("bf16x3", "bf16") else "tcn_mfma_f32_kernel"
+        return "stem_mfma_f32_kernel" if math == "f32" else ("stem_bf16_v4_kernel" if v4 else "stem_mfma_bf16_kernel")
+
+    def workload_key(math):
+        return f"{int(clips_per_launch)}x{T}x{V} {math} {'two-stage' if args.no_fuse else 'fused'} {args.layout}"
+
+    def roofline(math, kms, launches, with_traffic):
+        if not kms:
+            return None
+        achieved = flops_clip * clips_per_launch / (kms * 1e-3)
+        peak = MFMA_PEAK[math]
+        kname = kernel_name(math)
+        roof = {"bound": "mfma", "kernel": kname,
+                "issued_over_algorithmic_flops": 3 if math == "bf16x3" else 1,
+                "achieved": round(achieved / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4),
+                "achieved_over_f32_matrix_peak": round(achieved / MFMA_PEAK["f32"], 3),
+                "kernel_ms": round(kms, 4), "launches_timed": launches,
+                "algorithmic_flops_per_launch": int(flops_clip * clips_per_launch),
+                "algorithmic_bytes_per_launch": int(bytes_clip * clips_per_launch),
+                "hbm_GBps_of_kernel": round(bytes_clip * clips_per_launch / (kms * 1e-3) / 1e9, 1)}
+        if with_traffic:
+            roof["traffic"], roof["traffic_source"] = profiled_traffic(kname, workload_key(math))
+        return roof
+
+    line = None
     if rank == 0:
-        clips_total = n_local * world * args.steps
-        value = clips_total / elapsed
-        bytes_clip = 4 * T * V * (3 + 128)                       # fused stem: x in + activation out
-        flops_clip = 2 * 128 * 128 * 9 * T * V + 2 * T * V * (3 * 3 * V + 128 * 13)   # temporal conv + graph conv
-        roof = None
-        if kern_ms:
-            achieved = flops_clip * n_local / (kern_ms * 1e-3)
-            peak = MFMA_PEAK[args.math]
-            from stgcn_amd import _capi
-            v4 = args.math in ("bf16x3", "bf16") and bool(_capi.lib().stgcn_stem_features_used(3, 128, T, V, 9, 3, F._flags(
-                {"bf16x3": F.MATH_BF16X3, "bf16": F.MATH_BF16}.get(args.math, 0), False)))
-            kname = "stem_mfma_f32_kernel" if args.math == "f32" else ("stem_bf16_v4_kernel" if v4 else "stem_mfma_bf16_kernel")
-            peak_f32 = MFMA_PEAK["f32"]
-            default_cfg = n_local == 256 and T == 180 and V == 22 and not args.no_fuse and args.math in ("bf16x3", "f32")
-            roof = {"bound": "mfma", "kernel": kname,
-                    "issued_over_algorithmic_flops": 3 if args.math == "bf16x3" else 1,
-                    "achieved": round(achieved / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": profiled_traffic(kname, default_cfg),
-                    "achieved_over_f32_matrix_peak": round(achieved / peak_f32, 3),
-                    "kernel_ms": round(kern_ms, 4), "launches_timed": timer.count("stem_tail"),
-                    "algorithmic_flops_per_launch": flops_clip * n_local,
-                    "algorithmic_bytes_per_launch": bytes_clip * n_local,
-                    "hbm_GBps_of_kernel": round(bytes_clip * n_local / (kern_ms * 1e-3) / 1e9, 1)}
+        value = n_global * args.steps / elapsed
+        if strong:
+            workload = (f"BASELINE configs[4]: ONE synthetic batch (N={n_global},3,{T},{V}) DP-sharded over {world} GPU(s), "
+                        f"{n_local} clips on this rank in sub-batches of <= {sub}")
+        else:
+            workload = (f"SHREC'17-shape stem forward: V={V}, T={T}, {n_local} clips/GPU "
+                        f"(BASELINE configs[1] batch at 1 GPU; weak-scaled)")
         line = {
             "metric": "clips/sec ST-GCN forward", "value": round(value, 1), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": {"f32": "f32", "f32_valu": "f32", "bf16": "bf16",
-                      "bf16x3": "bf16x3 (fp32 operands split hi+lo bf16, 3 MFMAs, fp32 accumulate)"}[args.math],
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": DTYPE_NAME[args.math],
             "data": "synthetic randn clips (N,3,T,V), seeded random-init weights",
-            "config": {"workload": f"SHREC'17-shape stem forward: V={V}, T={T}, {n_local} clips/GPU "
-                                   f"(BASELINE configs[1] batch at 1 GPU; weak-scaled)",
-                       "clips_per_gpu": n_local, "global_clips": n_local * world, "T": T, "V": V,
+            "config": {"workload": workload, "clips_per_gpu": n_local, "global_clips": n_global, "T": T, "V": V,
+                       "stem_passes_per_step": launches_per_step, "workload_key": workload_key(args.math),
+                       "csrc_digest": csrc_digest(),
                        "math": args.math, "fused": not args.no_fuse, "layout": args.layout, "parallelism": f"dp{world}",
                        "parity": "1e-4 rel fp32 vs CPU oracle (tests/test_gpu_parity.py)"},
             "hbm_frac": round(value / world * bytes_clip / HBM_PEAK, 5),
             "mfma_frac": round(value / world * flops_clip / MFMA_PEAK[args.math], 4),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roofline(args.math, kern_ms, n_launch, True),
         }
+
+    # ---- second, longer block: where the figure settles once the clocks have ramped -------------------------
+    if args.steady_steps > 0:
+        e2, k2, n2, _ = timed_block(args.steady_steps, 0)
+        if rank == 0:
+            line["steady_state"] = {"steps": args.steady_steps, "ms_per_step": round(e2 / args.steady_steps * 1e3, 4),
+                                    "value": round(n_global * args.steady_steps / e2, 1),
+                                    "kernel_ms": None if k2 is None else round(k2, 4),
+                                    "roofline_frac": None if not k2 else round(
+                                        flops_clip * clips_per_launch / (k2 * 1e-3) / MFMA_PEAK[args.math], 4)}
+
+    # ---- exact-fp32 arithmetic, same workload, short block -----------------------------------------------------
+    if args.alt_steps > 0 and args.math != "f32":
+        stgcn_amd.set_math_mode(tcn, "f32")
+        e3, k3, n3, out3 = timed_block(args.alt_steps, 5)
+        assert torch.isfinite(out3).all()
+        stgcn_amd.set_math_mode(tcn, args.math)
+        if rank == 0:
+            v3 = n_global * args.alt_steps / e3
+            line["alt"] = {"dtype": "f32", "steps": args.alt_steps, "warmup": 5,
+                           "ms_per_step": round(e3 / args.alt_steps * 1e3, 4), "value": round(v3, 1),
+                           "mfma_frac": round(v3 / world * flops_clip / MFMA_PEAK["f32"], 4),
+                           "roofline": roofline("f32", k3, n3, False)}
+
+    if rank == 0:
+        if cpu_state is not None:
+            line["cpu_baseline"], line["cpu_oracle"] = cpu_legs(*cpu_state, T, V, args.cpu_clips, 5)
+        else:
+            line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -448,12 +448,17 @@ static unsigned tcn_dgrad_flags(int Cin, int Cout, int Tout, int V, int K, unsig
     return math;
 }
 
+// The input gradient of a stride-1 block is the forward kernel on the flipped weights ONLY for odd K: the transposed
+// conv pads K-1-pad frames, which equals the forward's pad = (K-1)/2 when K is odd.  With an even K the forward drops a
+// frame (Tout = T-1) and that shortcut would write T-2 misaligned frames: even K runs the general VALU dgrad instead.
+static bool tcn_dgrad_by_forward(int K, int stride) { return stride == 1 && (K & 1) == 1; }
+
 size_t stgcn_tcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || K <= 0 || stride <= 0) return 0;
     const int Tout = (T + 2 * ((K - 1) / 2) - K) / stride + 1;
     if (Tout < 1) return 0;
     size_t b = tcn_bwd_small_bytes(Cin, Cout) + align_up((size_t)N * Cout * Tout * V * sizeof(float), 256);
-    if (stride == 1)
+    if (tcn_dgrad_by_forward(K, stride))
         b += align_up((size_t)Cout * Cin * K * sizeof(float), 256) +
              align_up(tcn_packed_bytes(Cout, Cin, K, tcn_dgrad_flags(Cin, Cout, Tout, V, K, flags)), 256);
     return b + tcn_wgrad_ws_bytes(N, Cin, Cout, T, V, K, stride, flags);
@@ -494,7 +499,7 @@ int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, con
         if (rc != STGCN_OK) return rc;
     }
     if (dx != nullptr) {
-        if (stride == 1) {   // dx = conv_t(dz, flipped W): the forward kernels, raw output
+        if (tcn_dgrad_by_forward(K, stride)) {   // dx = conv_t(dz, flipped W): the forward kernels, raw output
             float *Wf = (float *)p;
             p += align_up((size_t)Cout * Cin * K * sizeof(float), 256);
             const unsigned dfl = tcn_dgrad_flags(Cin, Cout, Tout, V, K, flags);
@@ -512,7 +517,7 @@ int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, con
             rc = launch_tcn_dgrad_valu(dz, W, dx, N, Cin, Cout, T, V, K, stride, Tout, st);
             if (rc != STGCN_OK) return rc;
         }
-    } else if (stride == 1) {
+    } else if (tcn_dgrad_by_forward(K, stride)) {
         p += align_up((size_t)Cout * Cin * K * sizeof(float), 256) +
              align_up(tcn_packed_bytes(Cout, Cin, K, tcn_dgrad_flags(Cin, Cout, Tout, V, K, flags)), 256);
     }

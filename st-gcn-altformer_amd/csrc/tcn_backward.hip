@@ -467,6 +467,7 @@ struct WgradPlan {
 inline WgradPlan plan_wgrad(int N, int Cin, int Cout, int T, int V, int K, int stride) {
     WgradPlan pl;
     if (stride != 1 || K > 2 * KHMAX - 1 || K < 1 || Cout % 128 != 0 || Cin % 32 != 0) return pl;
+    if ((K & 1) == 0) return pl;   // the matrix-core kernel indexes dz and x with one frame count (Tout == T: odd K only)
     if ((size_t)(Cin > Cout ? Cin : Cout) * T * V * 4 >= ((size_t)1 << 31)) return pl;   // per-clip buffer resources
     const int Vp = (V + 7) / 8 * 8;
     const int upf = Vp / 8;

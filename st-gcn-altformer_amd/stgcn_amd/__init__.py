@@ -8,9 +8,9 @@ and keep ``from model.unit_agcn import unit_agcn`` / ``from model.net import Uni
 from ._capi import (ABI_VERSION, LIB_PATH, MATH_BF16, MATH_BF16X3, MATH_F32, MATH_F32_VALU, OUT_BF16,
                     StgcnError, lib)
 from .graphs import HandGraph, LMDHGGraph, SHREGraph
-from .modules import (Unit2D, conv_init, disable_stem_fusion, enable_stem_fusion, import_class,
+from .modules import (FusedStemOutput, Unit2D, conv_init, disable_stem_fusion, enable_stem_fusion, import_class,
                       set_math_mode, set_output_layout, unit_agcn)
 
-__all__ = ["unit_agcn", "Unit2D", "conv_init", "import_class", "enable_stem_fusion", "disable_stem_fusion",
+__all__ = ["unit_agcn", "Unit2D", "FusedStemOutput", "conv_init", "import_class", "enable_stem_fusion", "disable_stem_fusion",
            "set_math_mode", "set_output_layout", "SHREGraph", "LMDHGGraph", "HandGraph", "lib", "StgcnError", "LIB_PATH",
            "ABI_VERSION", "MATH_F32", "MATH_BF16X3", "MATH_BF16", "MATH_F32_VALU", "OUT_BF16"]

@@ -45,12 +45,15 @@ def _wants_grad(mod: nn.Module, x: torch.Tensor) -> bool:
     return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mod.parameters()))
 
 
-def _check_input(mod: nn.Module, x: torch.Tensor, backward_ok: bool = False):
-    if not backward_ok and mod.training and _wants_grad(mod, x):
-        raise NotImplementedError(
-            f"{type(mod).__name__}: the HIP path implements the forward only (eval, and training-mode forward with "
-            "batch-statistics BatchNorm under torch.no_grad()); autograd/backward is not implemented "
-            "(SURVEY.md §8f rank 2)")
+def _check_input(mod: nn.Module, x: torch.Tensor, backward_ok: bool = False, bn_training: Optional[bool] = None):
+    """Refuse what the HIP path does not implement instead of answering wrongly.
+
+    ``bn_training``: whether the module's BatchNorm(s) run on batch statistics (``self.bn.training`` — the reference's
+    nn.BatchNorm2d decides per sub-module, so ``model.train()`` followed by ``bn.eval()`` freezes the statistics there
+    and must do so here).  Autograd exists for batch-statistics mode only (the training scripts' case,
+    train_sttran.py:176-191); with running statistics the kernels write plain tensors without a grad_fn, so a call that
+    expects gradients is refused rather than silently cut out of the graph (wrap inference in ``torch.no_grad()`` as
+    the reference's validation loops do, train_sttran.py:207-210)."""
     if not x.is_cuda:
         raise RuntimeError(
             f"{type(mod).__name__}: input is on {x.device}; the HIP path runs on the GPU only "
@@ -59,6 +62,68 @@ def _check_input(mod: nn.Module, x: torch.Tensor, backward_ok: bool = False):
         raise TypeError(f"{type(mod).__name__}: input must be float32 (got {x.dtype})")
     if x.dim() != 4:
         raise ValueError(f"{type(mod).__name__}: expected (N,C,T,V), got {tuple(x.shape)}")
+    if bn_training is None:
+        bn_training = mod.training
+    if _wants_grad(mod, x):
+        if not bn_training:
+            raise NotImplementedError(
+                f"{type(mod).__name__}: gradients were requested through running-statistics (eval-mode) BatchNorm. The HIP "
+                "backward covers batch-statistics mode (module.train()) only; run inference under torch.no_grad(), or "
+                "set requires_grad_(False) on the stem's parameters and input")
+        if not backward_ok:
+            raise NotImplementedError(
+                f"{type(mod).__name__}: no HIP backward for this configuration (Unit2D(dim=3)); the dim=2 temporal block "
+                "and unit_agcn have one (SURVEY.md §8f rank 2)")
+
+
+# ----------------------------------------------------------------------------------------
+class FusedStemOutput(torch.Tensor):
+    """What ``unit_agcn.forward`` returns while stem fusion is enabled: the result of ``tcn0(gcn0(x))`` already
+    computed by the fused kernel, typed so that ONLY its ``Unit2D`` can take it.
+
+    ``ST_GCN_AltFormer.forward`` does ``x = self.gcn0(x); x = self.tcn0(x)`` (ST_GCN_AltFormer.py:70-72); with fusion
+    the first call has nothing of its own to return (gcn0's activation never leaves the chip).  Handing out the final
+    tensor as a plain Tensor would be a trap: a forward hook, a residual branch or a cast between the two modules would
+    read tcn0's output as if it were gcn0's, or strip a marker and run the temporal conv twice.  So every torch
+    operation on this type raises; shape / dtype / device queries work; ``Unit2D.forward`` of the paired module unwraps
+    it.  Whoever needs gcn0's real activation calls ``disable_stem_fusion(gcn)`` (two-stage path)."""
+
+    _PASSIVE = None
+
+    @staticmethod
+    def wrap(t: torch.Tensor, consumer: "Unit2D") -> "FusedStemOutput":
+        with torch._C.DisableTorchFunctionSubclass():
+            out = t.as_subclass(FusedStemOutput)
+        out._stgcn_consumer = consumer
+        return out
+
+    def unwrap(self) -> torch.Tensor:
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor)
+
+    @classmethod
+    def _passive(cls):
+        if cls._PASSIVE is None:
+            T = torch.Tensor
+            cls._PASSIVE = {T.shape.__get__, T.dtype.__get__, T.device.__get__, T.is_cuda.__get__, T.ndim.__get__,
+                            T.requires_grad.__get__, T.grad_fn.__get__, T.is_leaf.__get__, T.layout.__get__,
+                            T.dim, T.size, T.stride, T.numel, T.is_contiguous, T.data_ptr, T.element_size,
+                            T.storage_offset, T.is_floating_point, T.__repr__, T.__len__, T._version.__get__}
+        return cls._PASSIVE
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if func in cls._passive():
+            with torch._C.DisableTorchFunctionSubclass():
+                if func is torch.Tensor.__repr__:
+                    a = args[0]
+                    return f"FusedStemOutput(shape={tuple(a.shape)}, dtype={a.dtype}, device={a.device})"
+                return func(*args, **(kwargs or {}))
+        raise RuntimeError(
+            f"{getattr(func, '__name__', func)}: this tensor is the fused ST-GCN stem's deferred result — unit_agcn returned "
+            "it for its paired Unit2D only (stgcn_amd.enable_stem_fusion), and gcn0's own activation was never written. "
+            "Pass it straight to that Unit2D, or call stgcn_amd.disable_stem_fusion(gcn) to get the two-stage path "
+            "(hooks, residual branches and feature extraction on gcn0 need it)")
 
 
 # ----------------------------------------------------------------------------------------
@@ -246,9 +311,19 @@ class unit_agcn(nn.Module):
         self._cache = st
         return st
 
+    def _bn_training(self) -> bool:
+        """Batch statistics or running statistics: decided by the BatchNorm sub-modules themselves, as nn.BatchNorm2d
+        does in the reference (``self.bn`` at model/unit_agcn.py:60,91 and ``self.down[1]`` at :54).  Mixed modes (one
+        frozen, one not) are refused."""
+        main = self.bn.training
+        if self._has_down() and self.down[1].training != main:
+            raise NotImplementedError("unit_agcn: self.bn and self.down[1] are in different modes (one .train(), one .eval()); "
+                                      "the HIP path normalises both with the same kind of statistics")
+        return main
+
     def _fusable(self, x) -> bool:
         t = self._fused_tcn
-        if t is None or getattr(self, "_is_replica", False) or t.training or not self._has_down():
+        if t is None or getattr(self, "_is_replica", False) or t.bn.training or not self._has_down():
             return False
         if t.dim != 2 or t.stride != 1 or t.conv.in_channels != self.out_channels \
                 or t.conv.out_channels != self.out_channels:
@@ -259,13 +334,16 @@ class unit_agcn(nn.Module):
         return F.stem_supported(C, self.out_channels, T, V, t.kernel_size, self.num_subset, t.math_mode)
 
     def forward(self, x):
-        _check_input(self, x, backward_ok=True)      # (_forward_train refuses the shapes without a HIP backward)
+        if isinstance(x, FusedStemOutput):
+            x.sum()                                  # raises the explanatory error
+        bn_training = self._bn_training()
+        _check_input(self, x, backward_ok=True, bn_training=bn_training)   # (_forward_train refuses shapes without a backward)
         if x.shape[1] != self.in_channels:
             raise RuntimeError(f"unit_agcn: expected {self.in_channels} input channels, got {x.shape[1]}")
         if x.shape[3] != self.PA.shape[-1]:
             raise RuntimeError(f"unit_agcn: input has {x.shape[3]} joints, adjacency has {self.PA.shape[-1]}")
         st = self._staged(x.device)
-        if not self.training and self._fusable(x):
+        if not bn_training and self._fusable(x):
             if not F._is_channels_last(x):     # the permuted (N,T,V,C) batch of ST_GCN_AltFormer.py:62-68 is read in place
                 x = x.contiguous()
             t = self._fused_tcn
@@ -280,10 +358,9 @@ class unit_agcn(nn.Module):
                                     ts["shift"], self.out_channels, t.kernel_size, t.math_mode, t.out_bf16,
                                     channels_last_out=t.channels_last_out)
             self.last_attention = P
-            out._stgcn_fused_for = t          # Unit2D.forward recognises its own pre-computed output
-            return out
+            return FusedStemOutput.wrap(out, t)   # only `t` (Unit2D.forward) can take it; any other use raises
         x = x.contiguous()
-        if self.training:
+        if bn_training:
             return self._forward_train(x, st)
         y, P = F.agcn_forward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"],
                               st["Wdown"], st["bdown"], st["bn_scale"], st["bn_shift"], st["down_scale"],
@@ -386,9 +463,13 @@ class Unit2D(nn.Module):
         return st["packed"][math_mode]
 
     def forward(self, x):
-        if getattr(x, "_stgcn_fused_for", None) is self:
-            return x                      # produced by the fused stem kernel in unit_agcn.forward
-        _check_input(self, x, backward_ok=self.dim == 2)
+        if isinstance(x, FusedStemOutput):
+            if getattr(x, "_stgcn_consumer", None) is not self:
+                raise RuntimeError("Unit2D: received the fused stem result of ANOTHER Unit2D (enable_stem_fusion pairs one "
+                                   "unit_agcn with one Unit2D); call disable_stem_fusion on that unit_agcn")
+            return x.unwrap()             # tcn0(gcn0(x)), computed by the fused stem kernel in unit_agcn.forward
+        bn_training = self.bn.training    # nn.BatchNorm2d's own flag, like the reference's self.bn(...) (model/net.py:52)
+        _check_input(self, x, backward_ok=self.dim == 2, bn_training=bn_training)
         if x.shape[1] != self.conv.in_channels:
             raise RuntimeError(f"Unit2D: expected {self.conv.in_channels} input channels, got {x.shape[1]}")
         if self.dim == 3:
@@ -399,9 +480,9 @@ class Unit2D(nn.Module):
         if mode != MATH_F32_VALU and not F.tcn_supported(Cin, self.conv.out_channels, T, V, self.kernel_size,
                                                          self.stride, mode):
             mode = MATH_F32_VALU
-        if self.training:
-            if self.dropout.p > 0:
-                x = self.dropout(x)          # torch's RNG-driven op (the stem always uses p = 0, model/net.py:45)
+        if self.dropout.p > 0 and self.dropout.training:
+            x = self.dropout(x)              # torch's RNG-driven op (the stem always uses p = 0, model/net.py:45)
+        if bn_training:
             bn = self.bn
             if bn.momentum is None or not bn.track_running_stats:
                 raise NotImplementedError("Unit2D: training-mode BatchNorm needs momentum and running statistics")
@@ -431,9 +512,11 @@ def enable_stem_fusion(gcn: unit_agcn, tcn: Unit2D) -> None:
     """Make ``tcn(gcn(x))`` run as ONE fused kernel pair (attention + fused stem).
 
     Both modules stay where they are (state_dict keys and the caller's forward are untouched):
-    ``gcn.forward`` computes the whole stem and tags the result, ``tcn.forward`` passes a tensor
-    carrying its own tag straight through.  Falls back to the two-stage path whenever the fused
-    kernel does not cover the shape, under nn.DataParallel replicas, or in training mode.
+    ``gcn.forward`` computes the whole stem and returns it as a ``FusedStemOutput`` — a tensor type on
+    which every operation raises — and ``tcn.forward`` unwraps it.  Anything else that touches gcn0's
+    return value (a forward hook, a residual branch as in TCN_GCN_unit, a cast) therefore fails loudly
+    instead of reading tcn0's activation as gcn0's.  Falls back to the two-stage path whenever the fused
+    kernel does not cover the shape, under nn.DataParallel replicas, or with batch-statistics BatchNorm.
     """
     object.__setattr__(gcn, "_fused_tcn", tcn)
 

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Whole-model fixture FROM THE IMPORTED REFERENCE: pins north_star's "bit-exact for class-index argmax" clause.
+
+Build container only (needs /root/reference; see make_golden.py for the rules: the reference is imported as it lies,
+run on CPU, only DATA is written — nothing of its source).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_model.py
+
+What it does: builds the reference's ``ST_GCN_AltFormer`` (model/AltFormer/ST_GCN_AltFormer.py:16-87; 14 classes,
+T=180, V=22, graph.SHRE 'spatial' — the constructor call of SHREC/ST_TS/train_sttran.py:75-82) for ``style`` 'ST' and
+'TS' from a fixed seed, randomises the STEM parameters exactly like make_golden.py (default init has bn.weight = 1e-6,
+which hides the graph conv), runs 8 seeded, structured skeleton clips through it in eval mode on CPU, and stores
+
+    skeleton (8,180,22,3), the stem's state_dict + fixed adjacency, samples/sums of the stem output z,
+    logits (8,14) and argmax (8,) per style, and the seeds.
+
+The transformer heads (32 M parameters) are NOT stored: they are out of scope for the HIP path and re-created from the
+seed by ``tools/argmax_check.py`` in this container, which feeds the GPU-produced stem output through them and checks
+the argmax (the reference cannot travel to the GPU box, so the check is split: GPU test writes z, container compares).
+
+Harness-side shims (the reference tree is untouched):
+  * ``torch.Tensor.cuda`` -> identity during the call (model/unit_agcn.py:75 on a CPU tensor);
+  * ``timm.models.layers`` is not installed and only ``DropPath`` (identity in eval), ``to_2tuple`` and
+    ``trunc_normal_`` are imported from it (model_ST.py:10, model_TS.py:12): a stub module with those three names is
+    put into ``sys.modules`` (SURVEY.md §8c caveat 2).
+"""
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, HERE)
+
+MODEL_SEED = 4242          # torch.manual_seed before constructing ST_GCN_AltFormer (stem first, then the heads)
+STEM_SEED = 4243           # generator of the stem randomisation and of the skeleton batch
+N_CLIPS, T, V, CLASSES = 8, 180, 22, 14
+
+
+def install_timm_stub():
+    if "timm.models.layers" in sys.modules:
+        return
+
+    class DropPath(torch.nn.Module):       # stochastic depth: identity outside training (the only mode used here)
+        def __init__(self, drop_prob=0.0):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            if self.training and self.drop_prob > 0:
+                raise RuntimeError("timm stub: DropPath in training mode is not modelled")
+            return x
+
+    layers = types.ModuleType("timm.models.layers")
+    layers.DropPath = DropPath
+    layers.to_2tuple = lambda v: v if isinstance(v, tuple) else (v, v)
+    layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    timm = types.ModuleType("timm")
+    models = types.ModuleType("timm.models")
+    timm.models, models.layers = models, layers
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers})
+
+
+def structured_clips(g):
+    """Eight clips that differ in scale, offset and motion frequency.  (With i.i.d. randn clips the randomly
+    initialised heads answer the same class for every clip with a wide margin — an argmax test that cannot fail; these
+    clips spread the TS head over three classes with top-1/top-2 margins down to 1e-3 of a logit.)"""
+    t = torch.arange(T, dtype=torch.float32).view(1, T, 1, 1) / T
+    amp = torch.logspace(-1, 1, N_CLIPS).view(N_CLIPS, 1, 1, 1)
+    freq = torch.randint(1, 12, (N_CLIPS, 1, V, 3), generator=g).float()
+    phase = torch.rand(N_CLIPS, 1, V, 3, generator=g) * 6.28
+    offset = torch.randn(N_CLIPS, 1, V, 3, generator=g) * torch.linspace(0, 3, N_CLIPS).view(N_CLIPS, 1, 1, 1)
+    return (amp * torch.sin(6.28 * freq * t + phase) + offset + 0.05 * torch.randn(N_CLIPS, T, V, 3, generator=g)).contiguous()
+
+
+def build_reference_model(style):
+    """(model, A_fixed): the reference whole model with a randomised stem, eval mode."""
+    install_timm_stub()
+    import make_golden as mg                                   # imports the reference's unit_agcn / Unit2D
+    from model.AltFormer.ST_GCN_AltFormer import ST_GCN_AltFormer   # reference
+    torch.manual_seed(MODEL_SEED)
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        model = ST_GCN_AltFormer(channel=3, num_class=CLASSES, num_frame=T, num_joints=V, style=style,
+                                 graph="graph.SHRE", graph_args={"labeling_mode": "spatial"})
+    g = torch.Generator().manual_seed(STEM_SEED)
+    mg.randomise_gcn(model.gcn0, g, model.gcn0.A.clone())      # A as the constructor left it (1e-6: the aliasing quirk)
+    mg.randomise_tcn(model.tcn0, g)
+    return model.eval(), structured_clips(g)
+
+
+def heads_logits(model, z):
+    """The transformer head of `model.style` on a stem output z (N,128,T,V) -> logits (N,classes)."""
+    with torch.no_grad():
+        return model.modelA(z) if model.style == "ST" else model.modelB(z)
+
+
+def main():
+    import make_golden as mg
+    out = {}
+    for style in ("ST", "TS"):
+        model, skel = build_reference_model(style)
+        grabbed = []
+        h = model.tcn0.register_forward_hook(lambda m, i, o: grabbed.append(o.detach().clone()))
+        with mg.cuda_is_identity(), torch.no_grad():
+            logits = model(skel)
+        h.remove()
+        z = grabbed[0]
+        assert torch.equal(heads_logits(model, z), logits)
+        if not out:                                            # the stem (and z) is identical for both styles
+            out["skeleton"] = skel.numpy()
+            out["A_fixed"] = model.gcn0.A.numpy().copy()
+            out.update(mg.sd_np(model.gcn0, "gcn."))
+            out.update(mg.sd_np(model.tcn0, "tcn."))
+            zn = z.numpy()
+            idx = mg.sample_idx(zn.size, 60000, STEM_SEED)
+            out["z_idx"], out["z_val"] = idx, zn.reshape(-1)[idx]
+            out["z_absmax"] = np.abs(zn).max()
+            out["z_sum"] = zn.astype(np.float64).sum()
+            out["z_sumsq"] = (zn.astype(np.float64) ** 2).sum()
+            out["z_clip0"] = zn[0, :, :12].copy()              # one dense corner for a direct look
+        else:
+            assert np.array_equal(out["skeleton"], skel.numpy())
+        ln = logits.numpy()
+        out[f"logits_{style}"] = ln
+        out[f"argmax_{style}"] = ln.argmax(1).astype(np.int64)
+        top2 = np.sort(ln, axis=1)[:, -2:]
+        out[f"margin_{style}"] = (top2[:, 1] - top2[:, 0]).astype(np.float32)   # top-1 minus top-2 logit per clip
+        print(style, "argmax", out[f"argmax_{style}"], "min margin", out[f"margin_{style}"].min())
+    out["model_seed"], out["stem_seed"] = MODEL_SEED, STEM_SEED
+    np.savez_compressed(os.path.join(HERE, "model_altformer_shre.npz"), **out)
+    print("wrote model_altformer_shre")
+
+
+if __name__ == "__main__":
+    main()

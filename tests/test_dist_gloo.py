@@ -98,38 +98,108 @@ def _grad_worker(rank, world, port, q):
     sd.init("gloo")
     torch.manual_seed(5)                                   # same weights on both ranks, rank-dependent gradients
     a, b = torch.nn.Conv2d(3, 8, (9, 1)), torch.nn.BatchNorm2d(8)
-    for i, p in enumerate(list(a.parameters()) + list(b.parameters())):
+    ps = list(a.parameters()) + list(b.parameters())
+    for i, p in enumerate(ps):
         p.grad = torch.full_like(p, float(rank + 1)) * (i + 1) + torch.arange(p.numel(), dtype=torch.float32).view_as(p) * rank
-    b.bias.grad = None                                     # a parameter without gradient is skipped, not zero-filled
+    if rank == 0:
+        b.bias.grad = None                                 # missing on ONE rank only: must be zero-filled, not skipped
+    b.weight.requires_grad_(False)                         # frozen on both ranks: not exchanged, grad untouched
+    frozen = b.weight.grad.clone()
+    n_buckets = len(sd._bucketize(sd._trainable([a, b]), 32 << 20, 2))
     n = sd.all_reduce_grads([a, b])
     sd.barrier()
-    q.put((rank, n, [None if p.grad is None else p.grad.numpy() for p in list(a.parameters()) + list(b.parameters())]))
+    assert torch.equal(b.weight.grad, frozen)
+    q.put((rank, n, n_buckets, [p.grad.numpy() for p in ps]))
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_gradient_all_reduce():
-    """One flat-bucket all-reduce leaves every rank with the mean of the ranks' gradients (the DDP exchange of the
-    training step)."""
+def _run_two(target, *extra):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, 2, port, *extra, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return res
+
+
+def test_two_rank_gradient_all_reduce():
+    """Bucketed async all-reduce leaves every rank with the mean of the ranks' gradients; a gradient missing on one rank
+    counts as zeros there (same bucket layout on every rank: ADVICE r1), frozen parameters stay out."""
+    res = _run_two(_grad_worker)
     shapes = [(8, 3, 9, 1), (8,), (8,), (8,)]
-    assert res[0][1] == res[1][1] == 8 * 27 + 8 + 8
+    assert res[0][1] == res[1][1] == 8 * 27 + 8 + 8          # conv weight + conv bias + bn bias (bn weight frozen)
+    assert res[0][2] >= 2                                     # never one whole-model bucket
     for i, shp in enumerate(shapes):
-        g0, g1 = res[0][2][i], res[1][2][i]
-        if i == 3:
-            assert g0 is None and g1 is None
-            continue
+        if i == 2:
+            continue                                          # frozen bn.weight, checked in the worker
+        g0, g1 = res[0][3][i], res[1][3][i]
         n = 1
         for d in shp:
             n *= d
         ar = torch.arange(n, dtype=torch.float32).view(shp)
-        want = (1.0 * (i + 1) + 2.0 * (i + 1) + ar) / 2          # mean of rank 0 and rank 1
+        r0 = 0.0 if i == 3 else 1.0 * (i + 1)                 # bn.bias.grad was None on rank 0
+        want = (r0 + 2.0 * (i + 1) + ar) / 2                  # mean of rank 0 and rank 1
         assert torch.allclose(torch.from_numpy(g0), want) and torch.allclose(torch.from_numpy(g1), want)
+
+
+def _reducer_worker(rank, world, port, mode, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, "st-gcn-altformer_amd"))
+    torch.set_num_threads(1)
+    from stgcn_amd import dist as sd
+    sd.init("gloo")
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 16, (3, 1), padding=(1, 0)), torch.nn.ReLU(),
+                              torch.nn.Conv2d(16, 16, (3, 1), padding=(1, 0)), torch.nn.ReLU(),
+                              torch.nn.Conv2d(16, 4, 1))
+    unused = torch.nn.Linear(5, 5)                          # never in the graph: its slots must travel as zeros
+    red = sd.GradReducer([net, unused], bucket_bytes=2048, mode=mode)
+    fired = []
+    for step in range(2):
+        x = torch.randn(4, 3, 6, 5, generator=torch.Generator().manual_seed(100 * step + rank))
+        if step == 1:
+            for p in net.parameters():
+                p.grad = None                               # what optimizer.zero_grad(set_to_none=True) does
+        else:
+            red.zero_grad()
+        net(x).square().mean().backward()
+        fired.append(sum(b["launched"] for b in red.buckets))
+        n = red.finish()
+    grads = [p.grad.clone().numpy() for p in list(net.parameters()) + list(unused.parameters())]
+    views = all(p.grad.data_ptr() == red._slot[id(p)][1].data_ptr() for p in red.params)
+    q.put((rank, n, len(red.buckets), fired, views, red.mode, grads))
+    red.remove()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["all_reduce", "rs_ag"])
+def test_two_rank_grad_reducer_overlapped_buckets(mode):
+    """GradReducer: gradients live in persistent bucket buffers, buckets fire from autograd hooks during the backward,
+    finish() completes the rest; result == mean over ranks of independently computed gradients."""
+    res = _run_two(_reducer_worker, mode)
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 16, (3, 1), padding=(1, 0)), torch.nn.ReLU(),
+                              torch.nn.Conv2d(16, 16, (3, 1), padding=(1, 0)), torch.nn.ReLU(),
+                              torch.nn.Conv2d(16, 4, 1))
+    want = None
+    for rank in range(2):
+        net.zero_grad()
+        x = torch.randn(4, 3, 6, 5, generator=torch.Generator().manual_seed(100 + rank))
+        net(x).square().mean().backward()
+        g = [p.grad.clone() for p in net.parameters()]
+        want = g if want is None else [a + b for a, b in zip(want, g)]
+    want = [w / 2 for w in want]
+    n_net = sum(p.numel() for p in net.parameters())
+    for r in res:
+        rank, n, n_buckets, fired, views, used_mode, grads = r
+        assert n == n_net + 30 and n_buckets >= 2 and views
+        assert fired[0] >= 1 and fired[1] >= 1        # at least one bucket went out from inside backward()
+        for got, w in zip(grads[:len(want)], want):
+            assert torch.allclose(torch.from_numpy(got), w, rtol=1e-5, atol=1e-7)
+        for got in grads[len(want):]:
+            assert not got.any()                      # the unused module: zeros in, zeros out

@@ -146,3 +146,37 @@ def test_no_product_import_of_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_fused_stem_output_type_refuses_everything_but_its_unit2d():
+    """Host logic of the fusion guard (no GPU needed): the deferred result can be inspected and handed to its paired
+    Unit2D, nothing else — any torch operation raises with an explanation (VERDICT r1 weak #12)."""
+    from stgcn_amd import FusedStemOutput, Unit2D
+    tcn, other = Unit2D(4, 4, 3), Unit2D(4, 4, 3)
+    payload = torch.randn(2, 4, 5, 6)
+    w = FusedStemOutput.wrap(payload, tcn)
+    assert isinstance(w, torch.Tensor) and tuple(w.shape) == (2, 4, 5, 6) and w.dtype == torch.float32
+    assert w.dim() == 4 and w.size(1) == 4 and w.data_ptr() == payload.data_ptr() and "FusedStemOutput" in repr(w)
+    for misuse in (lambda: w + 1, lambda: w.clone(), lambda: w.half(), lambda: torch.relu(w), lambda: w.detach(),
+                   lambda: w[0], lambda: w.numpy(), lambda: torch.cat([w, w]), lambda: other(w)):
+        with pytest.raises(RuntimeError):
+            misuse()
+    with pytest.raises(RuntimeError, match="disable_stem_fusion"):
+        w.mean()
+    out = tcn(w)                                           # the paired module unwraps; no kernel runs for it
+    assert type(out) is torch.Tensor and out.data_ptr() == payload.data_ptr()
+    assert torch.equal(out + 0, payload)
+
+
+def test_input_checks_order_and_messages():
+    from stgcn_amd import Unit2D, unit_agcn
+    m = Unit2D(8, 8, kernel_size=3).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):     # device first: a CPU tensor is never a grad question
+        m(torch.zeros(1, 8, 4, 4))
+    g = unit_agcn(8, 8, torch.rand(3, 4, 4))
+    g.bn.eval()
+    assert g._bn_training() is False and g.training             # statistics mode follows the BatchNorm sub-module
+    g2 = unit_agcn(3, 8, torch.rand(3, 4, 4))
+    g2.down[1].eval()
+    with pytest.raises(NotImplementedError, match="different modes"):
+        g2._bn_training()

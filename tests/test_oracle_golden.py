@@ -186,3 +186,42 @@ def test_oracle_autograd_vs_reference_strided_tcn_gradients():
     names = sorted(leaves)
     grads = torch.autograd.grad((z * torch.from_numpy(g["G"]).double()).sum(), [leaves[k] for k in names])
     _check_grads(dict(zip(names, grads)), g, 1e-4)
+
+
+# ---------------------------------------------------------------------------------------
+# the library-op CPU baseline (oracle/stgcn_cpu_ops.py, what bench.py times as `cpu_baseline`)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", GCN_CASES)
+def test_cpu_ops_agcn_vs_reference(case):
+    from oracle import stgcn_cpu_ops as co
+    g = load_golden(case)
+    p = so.agcn_params_from_state(sub_state(g, "gcn."), torch.from_numpy(g["A_fixed"]))
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        y = co.agcn_forward_ops(x, p)
+    parity_gate(y, g["y_eval"], TIGHT, f"{case} library ops vs reference")
+    parity_gate(y, so.agcn_forward(x, p), TIGHT, f"{case} library ops vs oracle")
+
+
+@pytest.mark.parametrize("case,stride", [("tcn_128_128_k9", 1), ("tcn_64_128_k9_s2", 2), ("tcn_64_128_k1_s2", 2),
+                                         ("tcn_128_128_k9_v46", 1), ("tcn_32_64_k5_nobias", 1)])
+def test_cpu_ops_tcn_vs_reference(case, stride):
+    from oracle import stgcn_cpu_ops as co
+    g = load_golden(case)
+    p = so.tcn_params_from_state(sub_state(g, "tcn."), stride=stride)
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        y = co.tcn_forward_ops(x, p)
+    parity_gate(y, g["y_eval"], TIGHT, f"{case} library ops vs reference")
+    parity_gate(y, so.tcn_forward(x, p), TIGHT, f"{case} library ops vs oracle")
+
+
+def test_cpu_ops_stem_equals_oracle():
+    """The thing bench.py times as the CPU baseline computes the same stem as the oracle (seeded, T=40)."""
+    from oracle import stgcn_cpu_ops as co
+    g = load_golden("stem_shre_T180")
+    gp = so.agcn_params_from_state(sub_state(g, "gcn."), torch.from_numpy(g["A_fixed"]))
+    tp = so.tcn_params_from_state(sub_state(g, "tcn."))
+    x = so.caller_layout(torch.from_numpy(g["skeleton"]))[:, :, :40].contiguous()
+    with torch.no_grad():
+        parity_gate(co.stem_forward_ops(x, gp, tp), so.stem_forward(x, gp, tp), TIGHT, "stem library ops vs oracle")

@@ -7,9 +7,9 @@ TAG=${1:-r01}; shift
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}/gpurun_out/prof_$TAG
 mkdir -p "$R"
-B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline $*"
+B="python3 bench.py --steps 10 --warmup 3 --no-extras $*"
 # the trace pass runs longer: the --stats average includes the warm-up launches (cold clocks), which 13 launches do not dilute
-rocprofv3 --kernel-trace --stats --output-format csv -d "$R/trace" -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline $* > "$R/trace.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/trace" -- python3 bench.py --steps 100 --warmup 10 --no-extras $* > "$R/trace.log" 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/pmc_fetch" -- $B > "$R/pmc_fetch.log" 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/pmc_write" -- $B > "$R/pmc_write.log" 2>&1 || exit 1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \

@@ -60,12 +60,17 @@ def main():
             if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
                 m["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
         out[k] = m
-    json.dump(out, open(os.path.join(dst, f"{tag}_counters.json"), "w"), indent=1, sort_keys=True)
     log = os.path.join(src, "trace.log")
     if os.path.exists(log):
         for line in open(log):
             if line.startswith("{") and '"metric"' in line:
-                json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
+                bench = json.loads(line)
+                json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
+                # what bench.py checks before quoting `roofline.traffic` from this file: same workload, same kernel sources
+                out["_meta"] = {"workload": bench["config"].get("workload_key"),
+                                "csrc_digest": bench["config"].get("csrc_digest"),
+                                "collected_by": "tools/collect_profiles.sh " + tag}
+    json.dump(out, open(os.path.join(dst, f"{tag}_counters.json"), "w"), indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(dst)))
 
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STGCN_ABI_VERSION 3
+#define STGCN_ABI_VERSION 4
 
 typedef enum {
     STGCN_OK = 0,
@@ -223,12 +223,18 @@ int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, con
                              int V, int K, int stride, unsigned flags, void *stream);
 
 /* ---- data-parallel harness -------------------------------------------------------------------
- * Per-rank reductions that the ranks all-reduce once per step (the data-parallel form of the
- * reference's accuracy reduction, SHREC/ST_TS/train_sttran.py:105-109): stats[0] = n_local,
- * stats[1] = sum probe, stats[2] = sum probe^2, stats[3] = 0, with probe[n][c] = out[n][c][0][0]
- * (`plane` = T*V elements between consecutive (n,c) planes).  One launch, one workgroup. */
+ * Per-rank reductions that the ranks all-reduce once per step — the data-parallel form of the
+ * reference's accuracy reduction get_acc (SHREC/ST_TS/train_sttran.py:105-109: np.argmax of the
+ * logits on the host, compared with the labels, summed): stats[0] = n_local, stats[1] = sum probe,
+ * stats[2] = sum probe^2, stats[3] = #{n : argmax_c logits[n][c] == labels[n]}, with
+ * probe[n][c] = out[n][c][0][0] (`plane` = T*V elements between consecutive (n,c) planes).
+ * logits (n_logits, classes) fp32 and labels (n_logits) int64 are optional (NULL: stats[3] = 0);
+ * pred (n_logits) int64, optional, receives the class indices.  argmax follows numpy: the lowest
+ * index among equal maxima, a NaN is the maximum.  `out` may be NULL when only the count is wanted.
+ * One launch, one workgroup. */
 int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int C, long plane,
-                     float n_local, void *stream);
+                     float n_local, const float *logits, const long long *labels, long long *pred,
+                     int n_logits, int classes, void *stream);
 
 #ifdef __cplusplus
 }

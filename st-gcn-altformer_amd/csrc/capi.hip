@@ -39,32 +39,57 @@ __global__ void bn_fold_kernel(const float *__restrict__ w, const float *__restr
     shift[c] = fmaf(centre, s, b[c]);
 }
 
-// per-rank reductions for the data-parallel harness: stats = [clips, sum(probe), sum(probe^2), 0] with
-// probe[n][c] = out[n][c][0][0]; one workgroup, one launch (replaces ~6 tiny torch kernels per step)
+// per-rank reductions for the data-parallel harness: stats = [clips, sum(probe), sum(probe^2), correct] with
+// probe[n][c] = out[n][c][0][0]; one workgroup, one launch (replaces ~6 tiny torch kernels per step).
+// correct = #{n : argmax_c logits[n][c] == labels[n]} — get_acc of SHREC/ST_TS/train_sttran.py:105-109 (np.argmax on the
+// host there).  np.argmax semantics: the LOWEST index among equal maxima, and a NaN counts as the maximum (first NaN wins).
+__device__ inline int argmax_row(const float *__restrict__ row, int classes) {
+    float best = row[0];
+    int arg = 0;
+    if (best != best) return 0;
+    for (int c = 1; c < classes; ++c) {
+        const float v = row[c];
+        if (v != v) return c;          // NaN: np.argmax / torch.argmax return its index
+        if (v > best) { best = v; arg = c; }
+    }
+    return arg;
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void step_stats_kernel(const void *__restrict__ out, float *__restrict__ stats,
-                                                          int NC, size_t plane, float n_local) {
-    __shared__ float red[2][4];
-    float s1 = 0.f, s2 = 0.f;
-    for (int e = threadIdx.x; e < NC; e += 256) {
-        float v;
-        if constexpr (BF16) v = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(out)[(size_t)e * plane] << 16);
-        else v = reinterpret_cast<const float *>(out)[(size_t)e * plane];
-        s1 += v;
-        s2 = fmaf(v, v, s2);
-    }
+                                                          int NC, size_t plane, float n_local,
+                                                          const float *__restrict__ logits,
+                                                          const long long *__restrict__ labels,
+                                                          long long *__restrict__ pred, int n_logits, int classes) {
+    __shared__ float red[3][4];
+    float s1 = 0.f, s2 = 0.f, hit = 0.f;
+    if (out != nullptr)
+        for (int e = threadIdx.x; e < NC; e += 256) {
+            float v;
+            if constexpr (BF16) v = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(out)[(size_t)e * plane] << 16);
+            else v = reinterpret_cast<const float *>(out)[(size_t)e * plane];
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+        }
+    if (logits != nullptr)
+        for (int n = threadIdx.x; n < n_logits; n += 256) {
+            const int a = argmax_row(logits + (size_t)n * classes, classes);
+            if (pred != nullptr) pred[n] = a;
+            if (labels != nullptr && labels[n] == (long long)a) hit += 1.f;
+        }
     for (int o = 32; o > 0; o >>= 1) {
         s1 += __shfl_down(s1, o, 64);
         s2 += __shfl_down(s2, o, 64);
+        hit += __shfl_down(hit, o, 64);
     }
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; }
+    if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; red[2][w] = hit; }
     __syncthreads();
     if (threadIdx.x == 0) {
         stats[0] = n_local;
         stats[1] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         stats[2] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        stats[3] = 0.f;
+        stats[3] = red[2][0] + red[2][1] + red[2][2] + red[2][3];   // exact: a count below 2^24
     }
 }
 
@@ -526,14 +551,23 @@ int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, con
 }
 
 int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int C, long plane, float n_local,
+                     const float *logits, const long long *labels, long long *pred, int n_logits, int classes,
                      void *stream) {
-    REQUIRE_PTR(out); REQUIRE_PTR(stats); REQUIRE_POS(N); REQUIRE_POS(C); REQUIRE_POS(plane);
+    REQUIRE_PTR(stats);
+    if (out != nullptr) { REQUIRE_POS(N); REQUIRE_POS(C); REQUIRE_POS(plane); }
+    if (logits != nullptr) {
+        REQUIRE_POS(n_logits); REQUIRE_POS(classes);
+        if (n_logits >= (1 << 24)) return fail(STGCN_ERR_UNSUPPORTED, "step_stats: %d rows of logits per call", n_logits);
+    } else if (labels != nullptr || pred != nullptr) {
+        return fail(STGCN_ERR_ARG, "step_stats: labels / pred given without logits");
+    }
+    if (out == nullptr && logits == nullptr) return fail(STGCN_ERR_ARG, "step_stats: neither out nor logits given");
     if (out_is_bf16)
         hipLaunchKernelGGL(step_stats_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, out, stats, N * C,
-                           (size_t)plane, n_local);
+                           (size_t)plane, n_local, logits, labels, pred, n_logits, classes);
     else
         hipLaunchKernelGGL(step_stats_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)stream, out, stats, N * C,
-                           (size_t)plane, n_local);
+                           (size_t)plane, n_local, logits, labels, pred, n_logits, classes);
     STGCN_LAUNCH_CHECK("step_stats_kernel");
     return STGCN_OK;
 }

@@ -45,23 +45,44 @@ def shard(batch: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 
 
 def step_stats(out: torch.Tensor, n_local: int, logits: Optional[torch.Tensor] = None,
-               labels: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Per-rank reductions to all-reduce: [clips, sum(probe), sum(probe^2), correct]."""
-    if out.is_cuda and logits is None and out.is_contiguous() and out.dtype in (torch.float32, torch.bfloat16):
-        # one HIP launch on the current stream (stgcn_step_stats) instead of half a dozen tiny torch kernels
+               labels: Optional[torch.Tensor] = None, pred: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-rank reductions to all-reduce: [clips, sum(probe), sum(probe^2), correct].
+
+    ``correct`` = number of clips whose ``argmax(logits)`` equals the label — ``get_acc`` of
+    SHREC/ST_TS/train_sttran.py:105-109 without the device-to-host copy: on the GPU one HIP launch
+    (stgcn_step_stats) produces all four numbers, the class indices optionally land in ``pred`` (int64).
+    Tie-breaking is numpy's (lowest index).  CPU tensors (gloo tests) use the torch formulation."""
+    if out.is_cuda:
         from ctypes import c_float, c_int, c_long, c_void_p
         from . import _capi
+        if not out.is_contiguous() or out.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("step_stats: `out` must be a contiguous fp32 / bf16 (N,C,T,V) tensor")
+        if logits is not None:
+            if logits.dtype != torch.float32 or not logits.is_contiguous() or logits.dim() != 2 or not logits.is_cuda:
+                raise ValueError("step_stats: logits must be a contiguous fp32 (N,classes) GPU tensor")
+            for t, nm in ((labels, "labels"), (pred, "pred")):
+                if t is not None and (t.dtype != torch.int64 or not t.is_contiguous() or t.numel() != logits.shape[0]
+                                      or t.device != logits.device):
+                    raise ValueError(f"step_stats: {nm} must be a contiguous int64 tensor with one entry per row of logits")
+        ptr = lambda t: c_void_p(0 if t is None else t.data_ptr())
         stats = torch.empty(4, device=out.device, dtype=torch.float32)
         plane = out[0, 0].numel()
         with torch.cuda.device(out.device):
             _capi.call("stgcn_step_stats", c_void_p(out.data_ptr()), c_int(out.dtype == torch.bfloat16),
                        c_void_p(stats.data_ptr()), c_int(out.shape[0]), c_int(out.shape[1]), c_long(plane),
-                       c_float(float(n_local)), c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
+                       c_float(float(n_local)), ptr(logits), ptr(labels if logits is not None else None),
+                       ptr(pred if logits is not None else None), c_int(0 if logits is None else logits.shape[0]),
+                       c_int(0 if logits is None else logits.shape[1]),
+                       c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
         return stats
     probe = out.reshape(out.shape[0], out.shape[1], -1)[:, :, 0].float()
     correct = out.new_zeros((), dtype=torch.float32)
-    if logits is not None and labels is not None:
-        correct = (logits.argmax(dim=1) == labels).sum().float()      # get_acc, train_sttran.py:105-109
+    if logits is not None:
+        am = logits.argmax(dim=1)
+        if pred is not None:
+            pred.copy_(am)
+        if labels is not None:
+            correct = (am == labels).sum().float()                    # get_acc, train_sttran.py:105-109
     return torch.stack([out.new_tensor(float(n_local), dtype=torch.float32), probe.sum(), probe.square().sum(),
                         correct])
 

@@ -427,6 +427,34 @@ def test_step_stats_kernel_matches_torch(dev):
                           rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("n,classes", [(8, 14), (300, 28), (1024, 14), (1, 2)])
+def test_step_stats_argmax_is_numpy_argmax(n, classes, dev):
+    """The correct-count of the HIP step_stats kernel == get_acc of train_sttran.py:105-109 (np.argmax on the host),
+    bit-exact class indices including ties (lowest index), NaN rows and +-inf."""
+    from stgcn_amd import dist as sd
+    gen = torch.Generator().manual_seed(n + classes)
+    logits = torch.randn(n, classes, generator=gen)
+    logits = (logits * 4).round() / 4                       # quarter steps: plenty of exact ties
+    if n >= 8:
+        logits[1] = 0.0                                     # all equal -> class 0
+        logits[2, classes - 1] = float("inf")
+        logits[3, :] = float("-inf")                        # all -inf -> class 0
+        logits[4, 1] = float("nan")                         # numpy: NaN is the maximum
+        logits[5, 0] = logits[5].max()                      # tie with a later class -> the lower index
+    want = np.argmax(logits.numpy(), axis=1)
+    labels = torch.from_numpy(want.copy())
+    flip = torch.rand(n, generator=gen) < 0.3
+    labels[flip] = (labels[flip] + 1) % classes
+    out = torch.randn(n, 4, 2, 3, generator=gen).to(dev)
+    pred = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    stats = sd.step_stats(out, n, logits.to(dev), labels.to(dev), pred).cpu()
+    assert np.array_equal(pred.cpu().numpy(), want)
+    assert float(stats[3]) == float((torch.from_numpy(want) == labels).sum())
+    assert float(stats[0]) == n
+    cpu = sd.step_stats(out.cpu(), n, logits, labels)       # the torch formulation used by the gloo tests
+    assert float(cpu[3]) == float(stats[3])
+
+
 # ---------------------------------------------------------------------------------------
 # training-mode forward (batch-statistics BatchNorm), against the reference's own train-mode outputs
 # ---------------------------------------------------------------------------------------

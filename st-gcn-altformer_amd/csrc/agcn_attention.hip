@@ -20,43 +20,62 @@ namespace stgcn {
 
 namespace {
 
-constexpr int TM = 5;  // register tile of G: TM rows x TN cols per thread
-constexpr int TN = 4;
 constexpr int MS_FLOATS = 128;  // LDS reserved for the S*(Cin+1)^2 bilinear matrices
+constexpr int GB = 16;          // Gram block edge: one v_mfma_f32_16x16x4_f32 accumulator
 
-// Column soft-max of Sm[s][v][w] over v, then P = soft + A_eff.  One thread per (s,w) column.
-__device__ __forceinline__ void softmax_columns_store(float *Sm, const float *__restrict__ A_eff,
-                                                      float *__restrict__ Pn, int S, int V, int s0,
-                                                      int tid, int nthreads) {
-    for (int e = tid; e < S * V; e += nthreads) {
-        const int s = e / V, w = e - s * V;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// Column soft-max of Sm[s][v][w] over v, then P = soft + A_eff, left in Sm (the caller copies it to global memory
+// coalesced and, in the folded kernel, feeds the feature pass from it).  SIXTEEN lanes per (s,w) column, each holding
+// up to 4 of its V <= 64 entries, max / sum through width-16 shuffles: with one thread per column (the first form) 66 of
+// 1,024 threads walked 22-long dependent chains of LDS reads and expf — 12 % of the kernel.
+__device__ __forceinline__ void softmax_columns(float *Sm, const float *__restrict__ A_eff, int S, int V, int s0,
+                                                int tid, int nthreads) {
+    const int sub = tid & 15;
+    for (int c = tid >> 4; c < S * V; c += nthreads >> 4) {
+        const int s = c / V, w = c - s * V;
         float *col = Sm + (size_t)s * V * V + w;
-        float m = col[0];
-        for (int v = 1; v < V; ++v) m = fmaxf(m, col[v * V]);
-        float sum = 0.f;
-        for (int v = 0; v < V; ++v) {
-            const float ex = expf(col[v * V] - m);
-            col[v * V] = ex;
-            sum += ex;
-        }
         const float *Ae = A_eff + (size_t)(s0 + s) * V * V + w;
-        float *Po = Pn + (size_t)s * V * V + w;
-        for (int v = 0; v < V; ++v) {
-            const float pv = col[v * V] / sum + Ae[v * V];
-            col[v * V] = pv;  // keep the final P in LDS for the feature pass
-            Po[v * V] = pv;
+        float val[4], adj[4];
+        float m = -__builtin_huge_valf();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = sub + 16 * i;
+            adj[i] = v < V ? Ae[v * V] : 0.f;            // issued first: the only global latency of this phase
+            val[i] = v < V ? col[v * V] : -__builtin_huge_valf();
+            m = fmaxf(m, val[i]);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            val[i] = (sub + 16 * i < V) ? expf(val[i] - m) : 0.f;
+            sum += val[i];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = sub + 16 * i;
+            if (v < V) col[v * V] = val[i] / sum + adj[i];
         }
     }
 }
 
-// TS = time slices: 256*TS threads; slice ts accumulates the frames t = ts (mod TS) of the Gram, the partial
-// tiles are then summed through LDS.  More waves per CU matter here: the grid is only one workgroup per clip.
-template <int MAXIT, int TS>
-__global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
+// NW waves per workgroup (16 or 8).  The Gram G = X~^T X~ runs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact
+// fp32 fma chains, the VALU rate without the VALU's operand traffic): G is cut into 16x16 blocks, only the upper triangle
+// is computed, wave w owns blocks w, w+NW, ... (at most MAXB) and walks the clip 4 frames per MFMA.  Both operands of a
+// block are the same kind of read — lane l takes X~[t0 + (l>>4)][16*I + (l&15)] — and with a row pitch of 16 (mod 32)
+// floats the four frame rows of a fragment fall on disjoint banks: no conflicts (the register-tiled VALU form spent
+// 36 % of its LDS cycles in bank conflicts and 23 % of the kernel in this phase).
+template <int MAXB, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_folded_kernel(
     const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
     const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
-    float *__restrict__ P, float *__restrict__ feat, int Cin, int T, int V, int inter_c, int S, int TC,
-    int Rp, int feat_slice_off, int sq_behind, int xsc, int xsp, float *__restrict__ xcopy, unsigned long long *dbg) {
+    float *__restrict__ P, float *__restrict__ feat, uint4 *__restrict__ pfrag, int Cin, int T, int V, int inter_c,
+    int S, int TC, int Rp, int feat_slice_off, int sq_behind, int xsc, int xsp, float *__restrict__ xcopy,
+    unsigned long long *dbg) {
     // x element (channel k, pixel p) of a clip sits at k*xsc + p*xsp: (T*V, 1) for (N,Cin,T,V), (1, Cin) for (N,T,V,Cin).
     // xcopy (optional): channel-major copy of x for kernels downstream that read it in that layout.
 #ifdef STGCN_ABLATION  // in-kernel cycle stamps (diagnostic builds only)
@@ -65,10 +84,11 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
 #define K1_STAMP(i)
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NTH = 256 * TS;
+    constexpr int NTH = 64 * NW;
     K1_STAMP(0)
     const int tid = threadIdx.x;
-    const int tl = tid & 255, ts = tid >> 8;  // Gram tile owner / time slice
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x;
     const int C1 = Cin + 1;
     const int R = Cin * V + 1;  // columns of X~ (last one is the constant 1)
@@ -101,20 +121,19 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
         // (the first __syncthreads() of the chunk loop below orders these reads before U is overwritten)
     }
 
-    const int nTr = (R + TM - 1) / TM, nTc = (R + TN - 1) / TN;
-    const int ntiles = nTr * nTc;
-    int r0[MAXIT], c0[MAXIT];
-    float acc[MAXIT][TM][TN];
+    // this wave's Gram blocks: linear index b = wave + i*NW over the upper triangle, rows first
+    const int nb = (R + GB - 1) / GB;
+    const int nblk = nb * (nb + 1) / 2;
+    int bI[MAXB], bJ[MAXB];
+    f32x4 acc[MAXB];
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-        const int t = tl + it * 256;
-        const int tt = (t < ntiles) ? t : 0;
-        r0[it] = (tt / nTc) * TM;
-        c0[it] = (tt % nTc) * TN;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[it][i][j] = 0.f;
+    for (int i = 0; i < MAXB; ++i) {
+        int b = wave + i * NW, I = 0;
+        if (b >= nblk) b = 0;                    // (idle slot: computes block 0 again, never stored)
+        while (b >= nb - I) { b -= nb - I; ++I; }
+        bI[i] = I;
+        bJ[i] = I + b;
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     const float *xn = x + (size_t)n * Cin * T * V;
@@ -173,20 +192,13 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
         }
         __syncthreads();
         K1_STAMP(2)
-#pragma unroll 4
-        for (int tt = ts; tt < tc; tt += TS) {  // (unrolled: the LDS reads of later frames overlap the FMAs)
-            const float *row = U + tt * Rp;
+        {
+            const float *frag = U + (lane >> 4) * Rp + (lane & 15);
+            for (int tt0 = 0; tt0 < tc; tt0 += 4) {     // (rows tc .. TC-1 of the chunk are zero: TC is a multiple of 4)
+                const float *row = frag + tt0 * Rp;
 #pragma unroll
-            for (int it = 0; it < MAXIT; ++it) {
-                float a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = row[r0[it] + i];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = row[c0[it] + j];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[it][i][j] = fmaf(a[i], b[j], acc[it][i][j]);
+                for (int i = 0; i < MAXB; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[bI[i] * GB], row[bJ[i] * GB], acc[i], 0, 0, 0);
             }
         }
     }
@@ -194,24 +206,22 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     K1_STAMP(3)
     float *Gs = U;           // [R][R]
     float *Sm = U + R * R;   // [S][V][V]
-    for (int sl = 0; sl < TS; ++sl) {  // sum the TS partial Grams, one slice at a time
-        if (ts == sl) {
+    // accumulators -> Gs, both triangles: lane holds G[16I + 4*(l>>4) + r][16J + (l&15)], r = 0..3
 #pragma unroll
-            for (int it = 0; it < MAXIT; ++it) {
-                if (tl + it * 256 < ntiles) {
+    for (int i = 0; i < MAXB; ++i) {
+        if (wave + i * NW < nblk) {
+            const int gj = bJ[i] * GB + (lane & 15);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            if (r0[it] + i < R && c0[it] + j < R) {
-                                float *gp = Gs + (r0[it] + i) * R + c0[it] + j;
-                                *gp = (sl == 0) ? acc[it][i][j] : *gp + acc[it][i][j];
-                            }
+            for (int r = 0; r < 4; ++r) {
+                const int gi = bI[i] * GB + 4 * (lane >> 4) + r;
+                if (gi < R && gj < R) {
+                    Gs[gi * R + gj] = acc[i][r];
+                    Gs[gj * R + gi] = acc[i][r];
                 }
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     K1_STAMP(4)
     const float denom = (float)(inter_c * T);  // A1.size(-1) at unit_agcn.py:84
     for (int e = tid; e < S * V * V; e += NTH) {
@@ -230,7 +240,12 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     }
     __syncthreads();
     K1_STAMP(5)
-    softmax_columns_store(Sm, A_eff, P + (size_t)n * S * V * V, S, V, 0, tid, NTH);
+    softmax_columns(Sm, A_eff, S, V, 0, tid, NTH);
+    __syncthreads();
+    {   // P (N,S,V,V): coalesced copy of the finished matrices
+        float *Pn = P + (size_t)n * S * V * V;
+        for (int e = tid; e < S * V * V; e += NTH) Pn[e] = Sm[e];
+    }
     K1_STAMP(6)
 
     // Optional feature pass for the fused stem (Cin = 3, S = 3 only): per pixel (t,w) the 12 graph-conv
@@ -238,6 +253,25 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     // constant 1 that multiplies the folded bias and 3 zeros; the 16 values are split into bf16 hi + lo residual
     // (the operand form of the stem kernel's matrix-core producer) -> feat[n][t*V+w] = 64 B per pixel, coalesced:
     // [hi f0-7][hi f8-15][lo f0-7][lo f8-15].
+    // Optional (instead of the feature pass): the attention matrices as matrix-core B fragments for the stem kernel that
+    // computes the features itself (stem_bf16_v4.hip, FK form): u_s[k][t][w] = sum_v x[k][t][v] P_s[v][w] is a
+    // (4 frames x 4 channels) x 32 x 16 product per v_mfma_f32_16x16x32_bf16, B[v][w'] = P_s[v][16h + w'].  Fragment
+    // f = (s*2 + h)*2 + (0: bf16 hi, 1: lo residual), lane l holds v = 8*(l>>4) .. +7 of column w = 16h + (l&15); zeros
+    // past V.  12 KiB per clip instead of 64 B per pixel (253 KiB at T=180, V=22).
+    if (pfrag != nullptr) {                    // (host side guarantees S == 3, V <= 32)
+        uint4 *pf = pfrag + (size_t)n * 12 * 64;
+        for (int e = tid; e < 6 * 64; e += NTH) {
+            const int sh = e >> 6, l = e & 63, s = sh >> 1, h = sh & 1;
+            const int w = 16 * h + (l & 15), v0 = 8 * (l >> 4);
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = (w < V && v0 + j < V) ? Sm[(s * V + v0 + j) * V + w] : 0.f;
+            uint4 hi, lo;
+            bf16k::split8(pv, hi, lo);
+            pf[(sh * 2 + 0) * 64 + l] = hi;
+            pf[(sh * 2 + 1) * 64 + l] = lo;
+        }
+    }
     if (feat == nullptr) return;
     // LDS operands of the feature loop, interleaved so that one ds_read_b128 brings what three ds_read_b32 did:
     //   Sq[v][w] = (P_0, P_1, P_2, -)[v][w]  and  Xq[pixel] = (x_0, x_1, x_2, -).  Xq lives in the dead Gram region;
@@ -247,13 +281,11 @@ __global__ __launch_bounds__(256 * TS) void attention_folded_kernel(
     float4 *Sq = reinterpret_cast<float4 *>(U + sq_off);
     float4 *Xq = reinterpret_cast<float4 *>(U) + (sq_behind ? 0 : V * V);
     const int TCF = (R * R - (sq_behind ? 0 : 4 * V * V)) / (4 * V);   // (R*R = (3V+1)^2 > 9 V^2: at least one frame)
-    __syncthreads();  // P complete in Sm
     for (int e = tid; e < V * V; e += NTH) Sq[e] = make_float4(Sm[e], Sm[V * V + e], Sm[2 * V * V + e], 0.f);
     // Each lane builds one 64-byte feature row; storing it directly is 16 B per lane at a 64-B stride (store-issue
     // bound, measured ~4 B/clk/CU).  Instead the wave parks its 64 rows (4 KiB) in a private LDS slice and writes
     // them back out lane-linear: four fully coalesced 1-KiB stores.
     uint4 *slice = reinterpret_cast<uint4 *>(smem + feat_slice_off) + (tid >> 6) * 256;
-    const int lane = tid & 63;
     uint4 *fo = reinterpret_cast<uint4 *>(feat) + (size_t)n * T * V * 4;
     for (int t0 = 0; t0 < T; t0 += TCF) {
         const int tcf = min(TCF, T - t0);
@@ -374,7 +406,10 @@ __global__ __launch_bounds__(256) void attention_generic_kernel(
         if (e < V * V) Sm[e] = acc[it] / denom;
     }
     __syncthreads();
-    softmax_columns_store(Sm, A_eff, P + ((size_t)n * S + s) * V * V, 1, V, s, tid, 256);
+    softmax_columns(Sm, A_eff, 1, V, s, tid, 256);
+    __syncthreads();
+    float *Pn = P + ((size_t)n * S + s) * V * V;
+    for (int e = tid; e < V * V; e += 256) Pn[e] = Sm[e];
 }
 
 }  // namespace
@@ -383,31 +418,33 @@ __global__ __launch_bounds__(256) void attention_generic_kernel(
 // launch geometry of the folded kernel (shared by the capability query and the launcher)
 struct FoldedPlan {
     bool ok = false;
-    int maxit = 0, ts = 0, TC = 0, Rp = 0, slice_off = 0, sq_behind = 0;
+    int maxb = 0, nw = 0, TC = 0, Rp = 0, slice_off = 0, sq_behind = 0;
     size_t lds = 0;
 };
 
-static FoldedPlan plan_folded_ts(int Cin, int T, int V, int inter_c, int S, bool with_features, int ts, bool sq_behind = false) {
+// nw = waves per workgroup (16 or 8)
+static FoldedPlan plan_folded_nw(int Cin, int T, int V, int inter_c, int S, bool with_features, int nw, bool sq_behind = false) {
     FoldedPlan pl;
     const int C1 = Cin + 1, R = Cin * V + 1;
-    const int nTr = ceil_div(R, TM), nTc = ceil_div(R, TN);
-    const int ntiles = nTr * nTc;
+    const int nb = ceil_div(R, GB), nblk = nb * (nb + 1) / 2;
     const size_t gs_floats = (size_t)R * R + (size_t)S * V * V + (sq_behind ? (size_t)4 * V * V + 4 : 0);
     pl.sq_behind = sq_behind ? 1 : 0;
-    if (Cin > 4 || S * C1 * C1 > MS_FLOATS || ntiles > 8 * 256) return pl;
+    if (Cin > 4 || S * C1 * C1 > MS_FLOATS || V > 64) return pl;
     if (with_features && (Cin != 3 || S != 3)) return pl;
-    pl.maxit = ceil_div(ntiles, 256);
-    pl.ts = ts;                                              // time slices: 1024 or 512 threads
-    pl.Rp = (nTr * TM > nTc * TN ? nTr * TM : nTc * TN) | 1; // odd row stride spreads the tile reads over banks
-    const size_t slices = with_features ? (size_t)4 * pl.ts * 4096 : 0;   // 4 KiB per wave for the coalesced feature rows
-    // chunk of frames held in LDS: the whole clip when it fits in ~96 KiB, else as many frames as do
+    pl.maxb = ceil_div(nblk, nw);                            // Gram blocks (accumulators) per wave
+    if (pl.maxb > 12) return pl;
+    pl.nw = nw;
+    pl.Rp = (nb | 1) * GB;                                   // >= nb*16 and = 16 (mod 32) floats: conflict-free fragment reads
+    const size_t slices = with_features ? (size_t)nw * 4096 : 0;   // 4 KiB per wave for the coalesced feature rows
+    // chunk of frames held in LDS: the whole clip when it fits in ~96 KiB, else as many frames as do (multiple of 4:
+    // one MFMA step contracts 4 frames)
     size_t budget = (size_t)96 * 1024 / 4;
     if (gs_floats > budget) budget = gs_floats;
     if ((MS_FLOATS + budget) * 4 + slices > (size_t)kLdsBytes) budget = ((size_t)kLdsBytes - slices) / 4 - MS_FLOATS;
     if (budget < gs_floats) return pl;                       // Gram + attention matrices must fit
-    int TC = (int)(budget / pl.Rp);
-    if (TC > T) TC = T;
-    if (TC < 1) return pl;
+    int TC = (int)(budget / pl.Rp) & ~3;
+    if (TC > (T + 3) / 4 * 4) TC = (T + 3) / 4 * 4;
+    if (TC < 4) return pl;
     size_t u_floats = (size_t)TC * pl.Rp;
     if (u_floats < gs_floats) u_floats = gs_floats;
     const size_t wl_floats = (size_t)2 * S * inter_c * C1;   // LDS copy of the embedding weights
@@ -420,19 +457,15 @@ static FoldedPlan plan_folded_ts(int Cin, int T, int V, int inter_c, int S, bool
     return pl;
 }
 
-// 1024 threads (4 time slices) where the register tiles and LDS allow, else 512 (wide frames: V = 46 with features)
+// 1024 threads where LDS allows, else 512 (wide frames: V = 46 with the feature slices)
 static FoldedPlan plan_folded(int Cin, int T, int V, int inter_c, int S, bool with_features) {
-    const int R = Cin * V + 1;
-    const int maxit = ceil_div(ceil_div(R, TM) * ceil_div(R, TN), 256);
-    if (maxit <= 4) {
-        if (with_features) {   // the interleaved P behind the Gram matrix: longer frame chunks in the feature pass
-            const FoldedPlan p4b = plan_folded_ts(Cin, T, V, inter_c, S, true, 4, true);
-            if (p4b.ok) return p4b;
-        }
-        const FoldedPlan p4 = plan_folded_ts(Cin, T, V, inter_c, S, with_features, 4);
-        if (p4.ok) return p4;
+    if (with_features) {   // the interleaved P behind the Gram matrix: longer frame chunks in the feature pass
+        const FoldedPlan p16b = plan_folded_nw(Cin, T, V, inter_c, S, true, 16, true);
+        if (p16b.ok && p16b.maxb <= 4) return p16b;
     }
-    return plan_folded_ts(Cin, T, V, inter_c, S, with_features, 2);
+    const FoldedPlan p16 = plan_folded_nw(Cin, T, V, inter_c, S, with_features, 16);
+    if (p16.ok && p16.maxb <= 4) return p16;
+    return plan_folded_nw(Cin, T, V, inter_c, S, with_features, 8);
 }
 
 // true when launch_attention can also emit the (N, T*V, 16) feature tensor (folded kernel, Cin = 3, S = 3)
@@ -442,29 +475,33 @@ bool attention_emits_features(int Cin, int V, int S) {
 
 int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
                      const float *Wb, const float *bb, float *P, float *feat, int N, int Cin, int T, int V,
-                     int inter_c, int S, hipStream_t st, bool x_ntvc, float *xcopy) {
+                     int inter_c, int S, hipStream_t st, bool x_ntvc, float *xcopy, void *pfrag) {
     const int xsc = x_ntvc ? 1 : T * V, xsp = x_ntvc ? Cin : 1;
+    if (pfrag != nullptr && (Cin != 3 || S != 3 || V > 32 || feat != nullptr))
+        return fail(STGCN_ERR_UNSUPPORTED, "attention: fragment output covers Cin=3, 3 subsets, V<=32 (got %d, %d, %d)", Cin, S, V);
     if (feat != nullptr && (Cin != 3 || S != 3))
         return fail(STGCN_ERR_UNSUPPORTED, "attention: the feature pass covers Cin=3, 3 subsets (got %d, %d)", Cin, S);
     const FoldedPlan pl = plan_folded(Cin, T, V, inter_c, S, feat != nullptr);
     if (feat != nullptr && !pl.ok)
         return fail(STGCN_ERR_UNSUPPORTED, "attention: V=%d too large for the feature pass", V);
+    if (pfrag != nullptr && !pl.ok) return fail(STGCN_ERR_UNSUPPORTED, "attention: V=%d outside the folded kernel", V);
     if (pl.ok) {
         const int TC = pl.TC, Rp = pl.Rp, slice_off = pl.slice_off;
         const size_t lds = pl.lds;
 #define LAUNCH_FOLDED(MI, TSL)                                                                          \
     do {                                                                                               \
         STGCN_HIP_CHECK(allow_lds((attention_folded_kernel<MI, TSL>), lds));                           \
-        hipLaunchKernelGGL((attention_folded_kernel<MI, TSL>), dim3(N), dim3(256 * TSL), lds, st, x, A_eff, \
-                           Wa, ba, Wb, bb, P, feat, Cin, T, V, inter_c, S, TC, Rp, slice_off, pl.sq_behind, xsc, xsp, xcopy, debug_buffer()); \
+        hipLaunchKernelGGL((attention_folded_kernel<MI, TSL>), dim3(N), dim3(64 * TSL), lds, st, x, A_eff, \
+                           Wa, ba, Wb, bb, P, feat, (uint4 *)pfrag, Cin, T, V, inter_c, S, TC, Rp, slice_off, pl.sq_behind, xsc, xsp, xcopy, debug_buffer()); \
     } while (0)
-        if (pl.ts == 4) {
-            if (pl.maxit <= 1) LAUNCH_FOLDED(1, 4);
-            else if (pl.maxit <= 2) LAUNCH_FOLDED(2, 4);
-            else LAUNCH_FOLDED(4, 4);
+        if (pl.nw == 16) {
+            if (pl.maxb <= 1) LAUNCH_FOLDED(1, 16);
+            else if (pl.maxb <= 2) LAUNCH_FOLDED(2, 16);
+            else LAUNCH_FOLDED(4, 16);
         } else {
-            if (pl.maxit <= 4) LAUNCH_FOLDED(4, 2);
-            else LAUNCH_FOLDED(8, 2);
+            if (pl.maxb <= 2) LAUNCH_FOLDED(2, 8);
+            else if (pl.maxb <= 6) LAUNCH_FOLDED(6, 8);
+            else LAUNCH_FOLDED(12, 8);
         }
 #undef LAUNCH_FOLDED
         STGCN_LAUNCH_CHECK("attention_folded_kernel");

@@ -241,10 +241,11 @@ int stgcn_stem_attention(const float *x, const float *A_eff, const float *Wa, co
     if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "stem: N=%d > 65535 clips per call", N);
     const size_t need = stem_ws_bytes(N, Cin, C, T, V, K, subsets, flags);
     if (ws_bytes < need) return fail(STGCN_ERR_WORKSPACE, "stem: workspace %zu B < %zu B", ws_bytes, need);
-    return launch_attention(x, A_eff, Wa, ba, Wb, bb, (float *)ws,
-                            stem_ws_features(ws, N, Cin, C, T, V, K, subsets, flags), N, Cin, T, V, inter_c, subsets,
+    float *fpart = stem_ws_features(ws, N, Cin, C, T, V, K, subsets, flags);   // feature rows, or attention fragments
+    const bool frags = fpart != nullptr && stem_v4_features_in_kernel(C, T, V, K, flags);
+    return launch_attention(x, A_eff, Wa, ba, Wb, bb, (float *)ws, frags ? nullptr : fpart, N, Cin, T, V, inter_c, subsets,
                             (hipStream_t)stream, (flags & STGCN_IN_NTVC) != 0,
-                            stem_ws_xcopy(ws, N, Cin, C, T, V, K, subsets, flags));
+                            stem_ws_xcopy(ws, N, Cin, C, T, V, K, subsets, flags), frags ? fpart : nullptr);
 }
 
 int stgcn_stem_tail_prepared(const float *x, const void *ws, size_t ws_bytes, const void *prep, const float *t_shift,

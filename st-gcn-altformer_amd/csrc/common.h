@@ -95,7 +95,8 @@ int launch_bn_fold(const float *w, const float *b, const float *rm, const float 
 
 int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
                      const float *Wb, const float *bb, float *P, float *feat, int N, int Cin, int T,
-                     int V, int inter_c, int S, hipStream_t st, bool x_ntvc = false, float *xcopy = nullptr);
+                     int V, int inter_c, int S, hipStream_t st, bool x_ntvc = false, float *xcopy = nullptr,
+                     void *pfrag = nullptr);   // pfrag: (N,12,64) x 16 B attention B-fragments instead of features
 
 int launch_agcn_expand(const float *x, const float *P, const float *Wd, const float *bd,
                        const float *Wdown, const float *bdown, const float *bn_scale,
@@ -123,8 +124,11 @@ bool stem_fused_supported(int Cin, int C, int T, int V, int K, int S, unsigned f
 // large-tile persistent bf16 stem (stem_bf16_v4.hip); consumes the feature tensor the attention kernel emits
 bool attention_emits_features(int Cin, int V, int S);
 bool stem_v4_supported(int Cin, int C, int T, int V, int K, int S, unsigned flags);
-int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, const float *shift, void *out, int N,
-                   int C, int T, int V, int K, unsigned flags, hipStream_t st);  // honours STGCN_OUT_NTVC
+// true: the kernel computes the graph-conv features itself from x and the attention fragments (`feat` then points at the
+// (N,12,64) x 16 B fragments the attention kernel wrote); false: `feat` is the (N,T*V) x 64 B feature tensor
+bool stem_v4_features_in_kernel(int C, int T, int V, int K, unsigned flags);
+int launch_stem_v4(const float *x, bool x_ntvc, const float *feat, const void *prep_w12, const void *Wp, const float *shift,
+                   void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st);  // honours STGCN_OUT_NTVC
 
 // stand-alone temporal conv in the large-tile persistent form (stem_bf16_v4.hip): K = 9, stride 1, Cout % 128 == 0
 bool tcn_v4_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);

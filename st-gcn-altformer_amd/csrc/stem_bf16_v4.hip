@@ -19,6 +19,16 @@
 //   * the producer relu(W12 . Fs^T) runs on the bf16 matrix cores as well (two v_mfma_f32_16x16x32_bf16 per
 //     16x16 block, all four hi/lo products).
 //
+//   * FK form (NJ = 2, the 256-pixel tile): the feature tile is not read from HBM at all.  The attention kernel leaves the
+//     clip's three attention matrices as bf16 hi/lo MFMA B fragments (12 KiB per clip); at the start of a tile waves
+//     compute u_s[k][t][w] = sum_v x[k][t][v] P_s[v][w] for the tile's frames as (4 frames x 4 channels) x 32 x 16
+//     products (v_mfma_f32_16x16x32_bf16, all four hi/lo terms): with rows ordered (frame, channel) and one
+//     accumulator per subset, ONE lane ends up holding all nine u values of its pixel (t,w) — no shuffles — adds the
+//     three x values, splits to bf16 hi/lo and writes the pixel's 64-byte row into Fs.  x is read straight from the
+//     caller's tensor (either layout) by buffer loads issued at the start of the previous tile's epilogue; the
+//     fragments arrive by LDS-DMA during its last channel chunk.  The 64-B-per-pixel feature tensor (253 KiB per clip
+//     written by the attention kernel and read 1.8x here) is gone; wide frames (NJ = 1) keep it.
+//
 // Everything else (LDS image layout, k-step = 16 channels of one tap, 2x2 MFMA blocks per wave, hi/lo split of the
 // produced activations) is as described in tcn_bf16.hip.
 #include "bf16_common.h"
@@ -61,9 +71,9 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 // (the producer reads its rows through L1 and splits them in registers), which is what makes the tile fit.
 template <int PB, int TERMS, bool BF16OUT, int NJ>
 __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
-    const float4 *__restrict__ feat, const float *__restrict__ W12, const uint4 *__restrict__ Wp,
-    const float *__restrict__ shift, void *y, int C, int T, int V, int ROWS, int tiles_per_clip, int ntiles,
-    int abl, unsigned long long *dbg) {
+    const float4 *__restrict__ feat, const float *__restrict__ x, int xsc, int xsp, const float *__restrict__ W12,
+    const uint4 *__restrict__ Wp, const float *__restrict__ shift, void *y, int C, int T, int V, int ROWS,
+    int tiles_per_clip, int ntiles, int abl, unsigned long long *dbg) {
 #ifdef STGCN_ABLATION  // in-kernel cycle stamps (diagnostic builds only; dbg == NULL otherwise)
 #define STGCN_STAMP(var) unsigned long long var = 0; if (dbg) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); }
 #define STGCN_ACC(slot, a, b) if (dbg) { tsum[slot] += (b) - (a); }
@@ -79,6 +89,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     const int wm = wave & 1, wn = wave >> 1;
     constexpr int NPX = 128 * NJ;            // output pixels per tile
     constexpr bool W12LDS = NJ == 2;
+    constexpr bool FK = NJ == 2;             // features computed in the kernel (`feat` = attention fragments)
     const int TV = T * V;
     const int nch = C / CCB;                 // channel chunks (C = 128 -> 8)
     const int nstage = nch * (KT4 / STG);    // weight stages per tile
@@ -91,11 +102,15 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     char *buf1 = buf0 + buf_bytes;
     // (the image buffers double as the epilogue's staging area, 8 KiB per wave; the feature tile is prefetched for
     //  the next tile while that epilogue runs, so it starts behind BOTH)
-    uint4 *Fs = reinterpret_cast<uint4 *>(buf0 + max(2 * buf_bytes, 8 * EPI_BYTES * NJ / 2));  // features as bf16 hi/lo: 4 planes of [ROWS] x 16 B
+    // FK: Fs is rebuilt AFTER the epilogue (behind a barrier), so the staging area may run into it; the fragments Pf,
+    // prefetched during the last chunk, sit behind everything the epilogue touches.
+    uint4 *Fs = reinterpret_cast<uint4 *>(buf0 + (FK ? 2 * buf_bytes : max(2 * buf_bytes, 8 * EPI_BYTES * NJ / 2)));  // features as bf16 hi/lo: 4 planes of [ROWS] x 16 B
+    const uint4 *Pf = reinterpret_cast<const uint4 *>(buf0 + max(2 * buf_bytes + 4 * ROWS * 16, 8 * EPI_BYTES * NJ / 2));   // FK: 12 fragments
     // LDS byte addresses for the DMA destinations (M0), derived from the array base by plain arithmetic
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem4;
     const unsigned ring_lds = lds0 + (unsigned)(ring - smem4);
     const unsigned fs_lds = lds0 + (unsigned)(reinterpret_cast<char *>(Fs) - smem4);
+    const unsigned pf_lds = lds0 + (unsigned)(reinterpret_cast<const char *>(Pf) - smem4);
 
     const int cg = blockIdx.y;               // 128-channel group of the output
     // weight fragment this wave DMAs each tap: f = wave -> m-block (f>>1), image (f&1)
@@ -127,6 +142,94 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             if (j >= g.span || gi < 0 || gi >= TV) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Fs[(size_t)q * ROWS + j] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+
+    // ---- FK: features of a tile from x and the clip's attention fragments ------------------------------------
+    struct XRegs { float xa[8]; float xp[2][3]; };
+    auto dma_pfrag = [&](int tile) {         // 12 KiB: the clip's fragments -> Pf
+        const int n = tile / tiles_per_clip;
+        const uint4 *src = reinterpret_cast<const uint4 *>(feat) + (size_t)n * 12 * 64 + lane;
+        for (int f = wave; f < 12; f += 8) dma16(src + f * 64, pf_lds + f * FRAG);
+    };
+    // M-block mb = tile frames 4mb .. 4mb+3 (frame 0 = the first halo frame); as A operand lane l holds row (frame
+    // (l&15)>>2, channel l&3) and joints 8*(l>>4) .. +7; as accumulator it holds frame l>>4, joint column l&15.
+    auto load_x = [&](XRegs &xr, int tile, int mb) {
+        int lane = tid & 63;                 // opaque per call: keeps the lane-only address terms out of scratch (see epilogue)
+        asm volatile("" : "+v"(lane));
+        const int n = tile / tiles_per_clip;
+        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NPX);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x + (size_t)n * 3 * TV), 0, (unsigned)(3 * TV * 4), 0x00020000);
+        const int tf = g.t_first - (KT4 - 1) / 2 + 4 * mb;
+        {
+            const int k = lane & 3, t = tf + ((lane & 15) >> 2), v0 = 8 * (lane >> 4);
+            const bool okr = k < 3 && t >= 0 && t < T;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned off = (okr && v0 + j < V) ? (unsigned)((k * xsc + (t * V + v0 + j) * xsp) * 4) : 0x7ffffff0u;
+                xr.xa[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+            }
+        }
+        {
+            const int t = tf + (lane >> 4);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int w = 16 * hh + (lane & 15);
+                const bool ok = t >= 0 && t < T && w < V;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned off = ok ? (unsigned)((k * xsc + (t * V + w) * xsp) * 4) : 0x7ffffff0u;
+                    xr.xp[hh][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+                }
+            }
+        }
+    };
+    auto feature_phase = [&](int tile, const XRegs &first) {
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        const int n = tile / tiles_per_clip;
+        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NPX);
+        const int need = min(ROWS, ((g.span + 15) >> 4) << 4);       // rows the producer will read
+        const int nmb = ((need + V - 1) / V + 3) >> 2;
+        for (int mb = wave; mb < nmb; mb += 8) {
+            XRegs xr = first;
+            if (mb != wave) load_x(xr, tile, mb);                    // (narrow frames only: more than 8 M-blocks)
+            uint4 xh, xl;
+            split8(xr.xa, xh, xl);
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, xh), al = __builtin_bit_cast(bf16x8, xl);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                if (16 * hh >= V) break;
+                f32x4 d[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, Pf[((s * 2 + hh) * 2 + 0) * 64 + lane]);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, Pf[((s * 2 + hh) * 2 + 1) * 64 + lane]);
+                    d[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bl, d[s], 0, 0, 0);
+                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d[s], 0, 0, 0);
+                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d[s], 0, 0, 0);
+                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d[s], 0, 0, 0);
+                }
+                const int w = 16 * hh + (lane & 15);
+                const int p = (4 * mb + (lane >> 4)) * V + w;        // pixel row of the tile
+                const int gi = g.origin + p;
+                const bool valid = p < g.span && gi >= 0 && gi < TV; // else: the temporal conv's zero padding
+                const float one = valid ? 1.f : 0.f;
+                const float fa[8] = {d[0][0] * one, d[0][1] * one, d[0][2] * one, d[1][0] * one,
+                                     d[1][1] * one, d[1][2] * one, d[2][0] * one, d[2][1] * one};
+                const float fb[8] = {d[2][2] * one, xr.xp[hh][0] * one, xr.xp[hh][1] * one, xr.xp[hh][2] * one, one, 0.f, 0.f, 0.f};
+                uint4 ha, la, hb, lb;
+                split8(fa, ha, la);
+                split8(fb, hb, lb);
+                if (w < V && p < ROWS) {
+                    Fs[p] = ha;
+                    Fs[(size_t)ROWS + p] = hb;
+                    Fs[(size_t)2 * ROWS + p] = la;
+                    Fs[(size_t)3 * ROWS + p] = lb;
+                }
             }
         }
     };
@@ -189,12 +292,22 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         W12q[(size_t)(2 + kh) * C + c] = lo;
     }
     int tile = blockIdx.x;
-    if (tile < ntiles) dma_features(tile);
-    dma_stage(0);
-    dma_wait();
-    __syncthreads();                          // W12q, Fs(tile), weight stage 0 landed
-    if (tile < ntiles) zero_invalid_rows(tile);
-    __syncthreads();
+    {
+        XRegs x0 = {};                        // (block scope: nothing of it stays live into the tile loop)
+        if constexpr (FK) {
+            if (tile < ntiles) { dma_pfrag(tile); load_x(x0, tile, wave); }
+        } else {
+            if (tile < ntiles) dma_features(tile);
+        }
+        dma_stage(0);
+        dma_wait();
+        __syncthreads();                      // W12q, Fs(tile) / Pf(tile), weight stage 0 landed
+        if (tile < ntiles) {
+            if constexpr (FK) feature_phase(tile, x0);
+            else zero_invalid_rows(tile);
+        }
+        __syncthreads();
+    }
 
 #ifdef STGCN_ABLATION
     if (STGCN_ABL(32))  // experiment: de-phase the CUs so their epilogue store bursts do not coincide
@@ -267,7 +380,10 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             const char *cur = (ch & 1) ? buf1 : buf0;
             char *nxt = (ch & 1) ? buf0 : buf1;
             const bool last = ch + 1 == nch;
-            if (last && next_tile < ntiles) dma_features(next_tile);   // Fs is idle during the last chunk
+            if (last && next_tile < ntiles) {                          // Fs / Pf are idle during the last chunk
+                if constexpr (FK) dma_pfrag(next_tile);
+                else dma_features(next_tile);
+            }
             load_b(b_cur, cur, 0);
 #pragma unroll
             for (int st = 0; st < KT4 / STG; ++st, ++gs) {
@@ -315,12 +431,23 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         // block through this wave's 8 KiB slice of the (now idle) image buffers and store 16 B per lane, so one
         // wave-instruction writes four 256-B channel rows.
         STGCN_STAMP(t_e0)
+        // Opaque copies of the tile's scalars: everything the epilogue derives from them (store addresses: 64-bit
+        // multiplies per lane) is then computed here.  Left visible, hipcc hoists that arithmetic above the channel loop
+        // and spills it across the loop; a scratch reload in front of the next tile's feature phase then waits
+        // (vmcnt(0)) for every store of this epilogue.
+        int n_e = n, q0_e = g.q0, qlast_e = g.q_last, lane_e = lane;   // (lane too: lane-only terms are kernel invariants)
+        asm volatile("" : "+s"(n_e), "+s"(q0_e), "+s"(qlast_e), "+v"(lane_e));
+        XRegs xnext;                          // (declared per tile and always fully written: dead across the loop back-edge)
+        if constexpr (FK) {                   // next tile's x: in flight while this tile's results are stored
+            load_x(xnext, min(next_tile, ntiles - 1), wave);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (!STGCN_ABL(4) && (abl & OPT_OUT_NTVC)) {
             // (N,T,V,C) output: the block is staged pixel-major ([32*NJ pixels][32 channels], 16-byte slots XOR-swizzled by
             // the pixel so the b128 accesses are conflict-free); a wave-instruction then writes 8 pixels x 128 B.
             float *stg = reinterpret_cast<float *>(buf0 + wave * (EPI_BYTES * NJ / 2));   // 32 ch x 32*NJ px per wave
-            const int qw = g.q0 + wn * 32 * NJ;
-            const int hh = lane >> 5;
+            const int qw = q0_e + wn * 32 * NJ;
+            const int hh = lane_e >> 5;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int ob = cg * 128 + (wm * 2 + m) * 32;
@@ -329,7 +456,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                     const float4 sh4 = *reinterpret_cast<const float4 *>(shift + ob + 8 * gq + 4 * hh);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        const int px = j * 32 + (lane & 31);
+                        const int px = j * 32 + (lane_e & 31);
                         const float4 v = make_float4(fmaxf(acc[m][j][4 * gq + 0] + sh4.x, 0.f), fmaxf(acc[m][j][4 * gq + 1] + sh4.y, 0.f),
                                                      fmaxf(acc[m][j][4 * gq + 2] + sh4.z, 0.f), fmaxf(acc[m][j][4 * gq + 3] + sh4.w, 0.f));
                         *reinterpret_cast<float4 *>(stg + px * 32 + (((2 * gq + hh) ^ (px & 7)) << 2)) = v;
@@ -337,11 +464,11 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                 }
 #pragma unroll
                 for (int it = 0; it < 4 * NJ; ++it) {
-                    const int idx = it * 64 + lane, px = idx >> 3, sl = idx & 7;
+                    const int idx = it * 64 + lane_e, px = idx >> 3, sl = idx & 7;
                     const float4 v = *reinterpret_cast<const float4 *>(stg + px * 32 + ((sl ^ (px & 7)) << 2));
                     const int q = qw + px;
-                    const size_t gidx = ((size_t)n * TV + q) * C + ob + 4 * sl;
-                    if (q <= g.q_last) {
+                    const size_t gidx = ((size_t)n_e * TV + q) * C + ob + 4 * sl;
+                    if (q <= qlast_e) {
                         if constexpr (BF16OUT) {
                             *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + gidx) =
                                 make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
@@ -354,24 +481,24 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         } else if (!STGCN_ABL(4)) {
             float *stg = reinterpret_cast<float *>(buf0 + wave * (EPI_BYTES * NJ / 2));   // 32 ch x 32*NJ px per wave
             constexpr int PW = 32 * NJ;                          // pixel columns of this wave
-            const int qw = g.q0 + wn * PW;                       // first of them
+            const int qw = q0_e + wn * PW;                       // first of them
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int ob = cg * 128 + (wm * 2 + m) * 32;     // first output channel of the block
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int cr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int cr = (r & 3) + 8 * (r >> 2) + 4 * (lane_e >> 5);
                     const float sh = shift[ob + cr];
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) stg[cr * PW + j * 32 + (lane & 31)] = fmaxf(acc[m][j][r] + sh, 0.f);
+                    for (int j = 0; j < NJ; ++j) stg[cr * PW + j * 32 + (lane_e & 31)] = fmaxf(acc[m][j][r] + sh, 0.f);
                 }
 #pragma unroll
                 for (int it = 0; it < 4 * NJ; ++it) {
-                    const int idx = it * 64 + lane, row = idx / (PW / 4), c4 = (idx % (PW / 4)) * 4;
+                    const int idx = it * 64 + lane_e, row = idx / (PW / 4), c4 = (idx % (PW / 4)) * 4;
                     const float4 v = *reinterpret_cast<const float4 *>(stg + row * PW + c4);
                     const int q = qw + c4;
-                    const size_t gidx = ((size_t)n * C + ob + row) * TV + q;
-                    if (q + 3 <= g.q_last && (!BF16OUT || (gidx & 1) == 0)) {  // (bf16: keep the 8-B store dword-aligned)
+                    const size_t gidx = ((size_t)n_e * C + ob + row) * TV + q;
+                    if (q + 3 <= qlast_e && (!BF16OUT || (gidx & 1) == 0)) {  // (bf16: keep the 8-B store dword-aligned)
                         if constexpr (BF16OUT) {
                             *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + gidx) =
                                 make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
@@ -382,15 +509,20 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
                         const float e4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (q + e <= g.q_last) store_out<BF16OUT>(y, gidx + e, e4[e]);
+                            if (q + e <= qlast_e) store_out<BF16OUT>(y, gidx + e, e4[e]);
                     }
                 }
             }
         }
         STGCN_STAMP(t_e1)
         STGCN_ACC(3, t_e0, t_e1)
-        if (next_tile < ntiles) {             // its feature rows landed at the last stage barrier
-            zero_invalid_rows(next_tile);
+        if (next_tile < ntiles) {
+            if constexpr (FK) {               // its fragments landed at the last stage barrier, its x during the stores
+                __syncthreads();              // every wave's staging reads are done (the staging runs into Fs)
+                feature_phase(next_tile, xnext);
+            } else {                          // its feature rows landed at the last stage barrier
+                zero_invalid_rows(next_tile);
+            }
             __syncthreads();
         }
         STGCN_STAMP(t_e2)
@@ -639,13 +771,21 @@ inline bool plan_v4_nj(int C, int T, int V, int K, int terms, int nj, V4Plan &pl
     int dt = ceil_div(np - 1, V);
     if (dt > T - 1) dt = T - 1;
     const int span = (dt + K) * V;
-    const int rows = (span + 63) / 64 * 64;          // feature DMA moves 64 rows per wave-instruction
+    const bool fk = nj == 2;                         // features computed in the kernel
+    if (fk && V > 32) return false;                  // (one 32-deep k-step over the joints, two 16-column halves)
+    // feature DMA moves 64 rows per wave-instruction; the in-kernel form only needs whole 16-pixel producer blocks
+    const int rows = fk ? (span + 15) / 16 * 16 : (span + 63) / 64 * 64;
     const int pb = ceil_div(ceil_div(span, 16), 8);  // producer blocks per wave per chunk (8 producing waves)
     if (pb > KT4) return false;
     const size_t buf = (size_t)rows * PXB * (terms == 3 ? 2 : 1);
     const size_t stage = (size_t)8 * EPI_BYTES * nj / 2;                       // epilogue staging: 8 waves x 32 ch x 32*nj px
-    const size_t img = 2 * buf > stage ? 2 * buf : stage;                      // images / epilogue staging
-    const size_t lds = (nj == 2 ? (size_t)C * W12P * 4 : 0) + 2 * STAGE_BYTES + img + (size_t)rows * 64;
+    size_t lds = (nj == 2 ? (size_t)C * W12P * 4 : 0) + 2 * STAGE_BYTES;
+    if (fk) {   // images | Fs (the staging may run into it) | attention fragments (behind the staging)
+        const size_t body = 2 * buf + (size_t)rows * 64;
+        lds += (body > stage ? body : stage) + 12 * FRAG;
+    } else {
+        lds += (2 * buf > stage ? 2 * buf : stage) + (size_t)rows * 64;       // images / epilogue staging, then Fs
+    }
     if (lds > (size_t)kLdsBytes) return false;
     pl.pb = pb;
     pl.rows = rows;
@@ -661,20 +801,20 @@ inline bool plan_v4(int C, int T, int V, int K, int terms, V4Plan &pl) {
 }
 
 template <int PB, int TERMS, int NJ>
-int launch_v4(const float4 *feat, const float *W12, const uint4 *Wp, const float *shift, void *y, int N, int C, int T,
-              int V, const V4Plan &pl, bool bf16out, int opt, int num_cu, hipStream_t st) {
+int launch_v4(const float4 *feat, const float *x, int xsc, int xsp, const float *W12, const uint4 *Wp, const float *shift,
+              void *y, int N, int C, int T, int V, const V4Plan &pl, bool bf16out, int opt, int num_cu, hipStream_t st) {
     const int ntiles = N * pl.tiles_per_clip;
     const int gx = ntiles < num_cu ? ntiles : num_cu;
     const dim3 grid(gx, C / 128, 1);
     if (bf16out) {
         auto kern = stem_bf16_v4_kernel<PB, TERMS, true, NJ>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
-        hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
+        hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, x, xsc, xsp, W12, Wp, shift, y, C, T, V, pl.rows,
                            pl.tiles_per_clip, ntiles, ablate_mask() | opt, debug_buffer());
     } else {
         auto kern = stem_bf16_v4_kernel<PB, TERMS, false, NJ>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
-        hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, W12, Wp, shift, y, C, T, V, pl.rows,
+        hipLaunchKernelGGL(kern, grid, dim3(NT4), pl.lds, st, feat, x, xsc, xsp, W12, Wp, shift, y, C, T, V, pl.rows,
                            pl.tiles_per_clip, ntiles, ablate_mask() | opt, debug_buffer());
     }
     STGCN_LAUNCH_CHECK("stem_bf16_v4_kernel");
@@ -749,8 +889,15 @@ bool stem_v4_supported(int Cin, int C, int T, int V, int K, int S, unsigned flag
     return plan_v4(C, T, V, K, math == STGCN_MATH_BF16X3 ? 3 : 1, pl) && attention_emits_features(Cin, V, S);
 }
 
-int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, const float *shift, void *out, int N,
-                   int C, int T, int V, int K, unsigned flags, hipStream_t st) {
+bool stem_v4_features_in_kernel(int C, int T, int V, int K, unsigned flags) {
+    const unsigned math = flags & STGCN_MATH_MASK;
+    V4Plan pl;
+    return (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) && plan_v4(C, T, V, K, math == STGCN_MATH_BF16X3 ? 3 : 1, pl) &&
+           pl.nj == 2;
+}
+
+int launch_stem_v4(const float *x, bool x_ntvc, const float *feat, const void *prep_w12, const void *Wp, const float *shift,
+                   void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st) {
     const unsigned math = flags & STGCN_MATH_MASK;
     const int terms = math == STGCN_MATH_BF16X3 ? 3 : 1;
     const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
@@ -764,9 +911,12 @@ int launch_stem_v4(const float *feat, const void *prep_w12, const void *Wp, cons
     const float4 *f4 = (const float4 *)feat;
     const float *W12 = (const float *)prep_w12;
     const uint4 *wp = (const uint4 *)Wp;
+    const int xsc = x_ntvc ? 1 : T * V, xsp = x_ntvc ? 3 : 1;   // element (channel k, pixel p) of a clip at k*xsc + p*xsp
+    if (pl.nj == 2 && (size_t)3 * T * V * 4 >= ((size_t)1 << 31))
+        return fail(STGCN_ERR_UNSUPPORTED, "stem v4: clip of T=%d V=%d exceeds a buffer resource", T, V);
 #define GO(PB, NJ)                                                                                              \
-    return terms == 3 ? launch_v4<PB, 3, NJ>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, opt, num_cu, st)     \
-                      : launch_v4<PB, 1, NJ>(f4, W12, wp, shift, out, N, C, T, V, pl, bf16out, opt, num_cu, st)
+    return terms == 3 ? launch_v4<PB, 3, NJ>(f4, x, xsc, xsp, W12, wp, shift, out, N, C, T, V, pl, bf16out, opt, num_cu, st)     \
+                      : launch_v4<PB, 1, NJ>(f4, x, xsc, xsp, W12, wp, shift, out, N, C, T, V, pl, bf16out, opt, num_cu, st)
     if (pl.nj == 1) {
         if (pl.pb <= 6) GO(6, 1);
         GO(9, 1);

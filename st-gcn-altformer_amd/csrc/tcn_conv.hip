@@ -598,13 +598,16 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
 }
 
 // workspace of the fused stem: [ P : N*S*V*V floats, 256-B aligned ] then ONE of
-//   [ features : N*T*V x 64 B (16 features as bf16 hi + lo) ]   when the large-tile kernel serves the shape, or
+//   [ features : N*T*V x 64 B (16 features as bf16 hi + lo) ]   when the large-tile kernel serves the shape and reads
+//                                                                features (wide frames), or
+//   [ fragments: N x 12 KiB (attention matrices as bf16 hi/lo MFMA B fragments) ]  when it computes them itself, or
 //   [ x copy   : N*Cin*T*V floats, channel-major ]              with STGCN_IN_NTVC on the kernels that read x themselves
 static size_t stem_ws_p_bytes(int N, int V, int S) { return align_up((size_t)N * S * V * V * sizeof(float), 256); }
 
 size_t stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {
     size_t b = stem_ws_p_bytes(N, V, S);
-    if (stem_v4_supported(Cin, C, T, V, K, S, flags)) b += (size_t)N * T * V * 16 * sizeof(float);
+    if (stem_v4_supported(Cin, C, T, V, K, S, flags))
+        b += stem_v4_features_in_kernel(C, T, V, K, flags) ? (size_t)N * 12 * 1024 : (size_t)N * T * V * 16 * sizeof(float);
     else if (flags & STGCN_IN_NTVC) b += (size_t)N * Cin * T * V * sizeof(float);
     return b;
 }
@@ -625,8 +628,8 @@ int launch_stem(const float *x, const float *P, const float *feat, const void *p
     const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
     if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "stem: N=%d > 65535 clips per call", N);
     if (feat != nullptr && stem_v4_supported(Cin, C, T, V, K, S, flags))
-        return launch_stem_v4(feat, prep, (const char *)prep + stem_w12_bytes(C), t_shift, out, N, C, T, V, K, flags,
-                              st);
+        return launch_stem_v4(x, (flags & STGCN_IN_NTVC) != 0, feat, prep, (const char *)prep + stem_w12_bytes(C), t_shift,
+                              out, N, C, T, V, K, flags, st);
     if (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) {
         if (Cin != 3 || S != 3)
             return fail(STGCN_ERR_UNSUPPORTED, "stem: fused kernel covers Cin=3, 3 subsets (got %d, %d)", Cin, S);

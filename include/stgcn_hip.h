@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STGCN_ABI_VERSION 4
+#define STGCN_ABI_VERSION 5
 
 typedef enum {
     STGCN_OK = 0,
@@ -180,14 +180,19 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
 /* save_zm / save_zd (N,Cout,T,V): the two pre-BatchNorm branches (sum_s conv_d_s(x P_s), conv_down(x)) — asking for
  * them selects the materialising path; save_stats (4*Cout): batch mean, invstd of `bn`, then of the down BatchNorm.
  * All optional (NULL).  The backward takes zm / zd or recomputes them (NULL): */
-/* recompute = 1: zm / zd are not supplied (the forward ran the moments path); 0: they are.  Returns 0 for a shape that
- * is not covered. */
+/* recompute: bit 0 = zm / zd are not supplied (the forward ran the moments path; they are rebuilt in the workspace);
+ * bit 1 = size for the generic path — needed when an input gradient is wanted (dx != NULL), with the identity
+ * residual, or for a shape outside the stem class (the call below picks the path from its arguments; size for what
+ * you will ask).  0 for an invalid size. */
 size_t stgcn_agcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets, int recompute);
 /* Gradients of every parameter of unit_agcn (model/unit_agcn.py:35-62) from dy (N,Cout,T,V) in training mode:
  * dWa/dWb (S,inter_c,Cin), dba/dbb (S,inter_c), dWd (S,Cout,Cin), dbd (S,Cout), dWdown (Cout,Cin), dbdown, the
- * two BatchNorms' dgamma/dbeta (main, then "dd" = down), dPA (S,V,V).  x is data: no dx.  zm / zd: the branches the
- * forward saved, or both NULL to have them rebuilt here.  Covers the stem's shape class (Cin = 3, 3 subsets,
- * Cout in {64,128,256}, down branch present); else STGCN_ERR_UNSUPPORTED. */
+ * two BatchNorms' dgamma/dbeta (main, then "dd" = down), dPA (S,V,V), and — optionally — dx (N,Cin,T,V), the gradient
+ * of the input that the deeper TCN_GCN_unit layers need (model/ST_TR/ST_TR_new.py:355-372); NULL when x is data.
+ * Identity residual (Cin == Cout, unit_agcn.py:57-58): pass NULL for Wdown, bdown, the down BatchNorm tensors, zd and
+ * the four down-gradient outputs.  zm / zd: the branches the forward saved, or NULL to have them rebuilt here.
+ * Two implementations: one fused kernel for the stem's shape class (Cin = 3, 3 subsets, Cout in {64,128,256}, down
+ * branch, no dx) and a chain of strided batched fp32-MFMA GEMMs for everything else (V <= 64, inter_c <= Cout/4). */
 int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *Wa, const float *ba,
                               const float *Wb, const float *bb, const float *Wd, const float *bd,
                               const float *Wdown, const float *bdown, const float *P, const float *zm,
@@ -195,8 +200,8 @@ int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *W
                               const float *dbn_weight, const float *dbn_bias, const float *save_stats,
                               const float *dy, float *dWa, float *dba, float *dWb, float *dbb, float *dWd,
                               float *dbd, float *dWdown, float *dbdown, float *dgamma, float *dbeta,
-                              float *ddgamma, float *ddbeta, float *dPA, void *ws, size_t ws_bytes, int N,
-                              int Cin, int Cout, int T, int V, int inter_c, int subsets, void *stream);
+                              float *ddgamma, float *ddbeta, float *dPA, float *dx, void *ws, size_t ws_bytes,
+                              int N, int Cin, int Cout, int T, int V, int inter_c, int subsets, void *stream);
 size_t stgcn_tcn_train_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
 /* save_z (N,Cout,T_out,V), save_mean, save_invstd (Cout): optional outputs for the backward — the raw
  * convolution conv_t(x)+b and the batch statistics, torch's save_mean / save_invstd.  NULL: not kept. */

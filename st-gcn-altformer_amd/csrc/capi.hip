@@ -356,11 +356,35 @@ static size_t agcn_bwd_small_bytes(int Cout) {
     return align_up((size_t)Cout * 3 * sizeof(double) + (size_t)Cout * 12 * sizeof(float), 256);
 }
 
+// identity residual: g = dy where relu's argument (s_m*zm + t_m) + x was positive  ->  dx (= dL/dx of the "+ x" term)
+__global__ static void identity_residual_grad_kernel(const float *__restrict__ zm, const float *__restrict__ x,
+                                                     const float *__restrict__ sm, const float *__restrict__ tm,
+                                                     const float *__restrict__ dy, float *__restrict__ dx, size_t total,
+                                                     int C, size_t plane) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)((e / plane) % C);
+    dx[e] = (fmaf(zm[e], sm[c], tm[c]) + x[e] > 0.f) ? dy[e] : 0.f;
+}
+
+// The fused single-kernel backward serves the stem's shape class when no input gradient is wanted; everything else
+// (any Cin / Cout / subsets, identity residual, dx) takes the generic GEMM chain.
+static bool agcn_bwd_use_fused(int N, int Cin, int Cout, int T, int V, int S, bool has_down, bool want_dx) {
+    return has_down && !want_dx && agcn_bwd_supported(N, Cin, Cout, T, V, S);
+}
+static size_t agcn_bwd_generic_bytes(int N, int Cin, int Cout, int T, int V, int S) {
+    const int inter_c = Cout / 4 > 0 ? Cout / 4 : 1;   // upper bound used for sizing: unit_agcn's coff_embedding = 4
+    return align_up(((size_t)2 * N * Cout * T * V + agcn_bwd_generic_ws_floats(N, Cin, Cout, T, V, inter_c, S)) * sizeof(float), 256);
+}
+
+// recompute: bit 0 = the two pre-BatchNorm branches are not supplied (rebuilt in the workspace); bit 1 = size for the
+// generic path (input gradient wanted / identity residual / a shape outside the stem class).  Never 0 for valid sizes.
 size_t stgcn_agcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets, int recompute) {
-    if (N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || subsets <= 0) return 0;
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || subsets <= 0 || V > 64) return 0;
+    const size_t branches = (recompute & 1) ? (size_t)2 * N * Cout * T * V * sizeof(float) : 0;
     const size_t part = agcn_bwd_part_bytes(N, Cin, Cout, T, V, subsets);
-    if (!part) return 0;                                   // shape not covered
-    return agcn_bwd_small_bytes(Cout) + align_up(part, 256) + (recompute ? (size_t)2 * N * Cout * T * V * sizeof(float) : 0);
+    if (part && !(recompute & 2)) return agcn_bwd_small_bytes(Cout) + align_up(part, 256) + branches;
+    return agcn_bwd_small_bytes(Cout) + agcn_bwd_generic_bytes(N, Cin, Cout, T, V, subsets) + branches;
 }
 
 int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *Wa, const float *ba, const float *Wb,
@@ -369,56 +393,93 @@ int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *W
                               const float *bn_bias, const float *dbn_weight, const float *dbn_bias,
                               const float *save_stats, const float *dy, float *dWa, float *dba, float *dWb, float *dbb,
                               float *dWd, float *dbd, float *dWdown, float *dbdown, float *dgamma, float *dbeta,
-                              float *ddgamma, float *ddbeta, float *dPA, void *ws, size_t ws_bytes, int N, int Cin, int Cout,
-                              int T, int V, int inter_c, int subsets, void *stream) {
+                              float *ddgamma, float *ddbeta, float *dPA, float *dx, void *ws, size_t ws_bytes, int N, int Cin,
+                              int Cout, int T, int V, int inter_c, int subsets, void *stream) {
     REQUIRE_PTR(x); REQUIRE_PTR(A_eff); REQUIRE_PTR(Wa); REQUIRE_PTR(ba); REQUIRE_PTR(Wb); REQUIRE_PTR(bb); REQUIRE_PTR(Wd);
-    REQUIRE_PTR(bd); REQUIRE_PTR(Wdown); REQUIRE_PTR(bdown); REQUIRE_PTR(P); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias);
-    REQUIRE_PTR(dbn_weight); REQUIRE_PTR(dbn_bias); REQUIRE_PTR(save_stats); REQUIRE_PTR(dy); REQUIRE_PTR(dWa); REQUIRE_PTR(dba);
-    REQUIRE_PTR(dWb); REQUIRE_PTR(dbb); REQUIRE_PTR(dWd); REQUIRE_PTR(dbd); REQUIRE_PTR(dWdown); REQUIRE_PTR(dbdown);
-    REQUIRE_PTR(dgamma); REQUIRE_PTR(dbeta); REQUIRE_PTR(ddgamma); REQUIRE_PTR(ddbeta); REQUIRE_PTR(dPA); REQUIRE_PTR(ws);
+    REQUIRE_PTR(bd); REQUIRE_PTR(P); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias);
+    REQUIRE_PTR(save_stats); REQUIRE_PTR(dy); REQUIRE_PTR(dWa); REQUIRE_PTR(dba);
+    REQUIRE_PTR(dWb); REQUIRE_PTR(dbb); REQUIRE_PTR(dWd); REQUIRE_PTR(dbd);
+    REQUIRE_PTR(dgamma); REQUIRE_PTR(dbeta); REQUIRE_PTR(dPA); REQUIRE_PTR(ws);
     REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(Cout); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(inter_c); REQUIRE_POS(subsets);
-    if ((zm == nullptr) != (zd == nullptr)) return fail(STGCN_ERR_ARG, "agcn_backward: give both saved branches or neither");
-    if (!agcn_bwd_supported(N, Cin, Cout, T, V, subsets))
-        return fail(STGCN_ERR_UNSUPPORTED,
-                    "agcn_backward: covers Cin=3, 3 subsets, Cout in {64,128,256}, a down branch (got Cin=%d S=%d Cout=%d V=%d)",
-                    Cin, subsets, Cout, V);
+    const bool has_down = Wdown != nullptr;
+    if (has_down) {
+        REQUIRE_PTR(bdown); REQUIRE_PTR(dbn_weight); REQUIRE_PTR(dbn_bias); REQUIRE_PTR(dWdown); REQUIRE_PTR(dbdown);
+        REQUIRE_PTR(ddgamma); REQUIRE_PTR(ddbeta);
+    } else if (Cin != Cout) {
+        return fail(STGCN_ERR_ARG, "agcn_backward: identity residual needs Cin == Cout (got %d, %d)", Cin, Cout);
+    }
+    if (V > 64) return fail(STGCN_ERR_UNSUPPORTED, "agcn_backward: V=%d > 64", V);
+    if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "agcn_backward: N=%d > 65535 clips per call", N);
+    if (inter_c > (Cout / 4 > 0 ? Cout / 4 : 1) && !agcn_bwd_use_fused(N, Cin, Cout, T, V, subsets, has_down, dx != nullptr))
+        return fail(STGCN_ERR_UNSUPPORTED, "agcn_backward: inter_c=%d > Cout/4 (workspace is sized for coff_embedding >= 4)", inter_c);
+    if (has_down ? ((zm == nullptr) != (zd == nullptr)) : (zd != nullptr))
+        return fail(STGCN_ERR_ARG, "agcn_backward: give both saved branches or neither (zd only with a down branch)");
+    const bool fused = agcn_bwd_use_fused(N, Cin, Cout, T, V, subsets, has_down, dx != nullptr);
     const bool recompute = zm == nullptr;
-    const size_t need = stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, subsets, recompute ? 1 : 0);
+    const size_t need = stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, subsets, (recompute ? 1 : 0) | (fused ? 0 : 2));
     if (ws_bytes < need) return fail(STGCN_ERR_WORKSPACE, "agcn_backward: workspace %zu B < %zu B", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    const size_t plane = (size_t)T * V;
+    const size_t plane = (size_t)T * V, total = (size_t)N * Cout * plane;
     double *sums = (double *)ws;
     float *coefm = (float *)(sums + 3 * Cout), *coefd = coefm + 3 * Cout, *sm_ = coefd + 3 * Cout, *tm_ = sm_ + Cout,
           *sd_ = tm_ + Cout, *td_ = sd_ + Cout, *ones = td_ + Cout, *zeros = ones + Cout;
-    float *part = (float *)((char *)ws + agcn_bwd_small_bytes(Cout));
+    char *body = (char *)ws + agcn_bwd_small_bytes(Cout);
+    const size_t body_bytes = fused ? align_up(agcn_bwd_part_bytes(N, Cin, Cout, T, V, subsets), 256)
+                                    : agcn_bwd_generic_bytes(N, Cin, Cout, T, V, subsets);
     int rc;
     if (recompute) {   // the forward kept no branches (moments path): rebuild them with the raw-mode expansion kernel
-        float *zmw = (float *)((char *)part + align_up(agcn_bwd_part_bytes(N, Cin, Cout, T, V, subsets), 256));
-        float *zdw = zmw + (size_t)N * Cout * plane;
+        float *zmw = (float *)(body + body_bytes);
+        float *zdw = zmw + total;
         hipLaunchKernelGGL(fill_ones_zeros_kernel, dim3(ceil_div(Cout, 256)), dim3(256), 0, st, ones, zeros, Cout);
         STGCN_LAUNCH_CHECK("fill_ones_zeros_kernel");
-        rc = launch_agcn_expand(x, P, Wd, bd, Wdown, bdown, ones, zeros, zeros, zeros, zmw, N, Cin, Cout, T, V, subsets, 1 | 2, st);
-        if (rc != STGCN_OK) return rc;
-        rc = launch_agcn_expand(x, P, Wd, bd, Wdown, bdown, zeros, zeros, ones, zeros, zdw, N, Cin, Cout, T, V, subsets, 1, st);
+        rc = launch_agcn_expand(x, P, Wd, bd, Wdown, bdown, ones, zeros, has_down ? zeros : nullptr, has_down ? zeros : nullptr,
+                                zmw, N, Cin, Cout, T, V, subsets, 1 | 2, st);
         if (rc != STGCN_OK) return rc;
         zm = zmw;
-        zd = zdw;
+        if (has_down) {
+            rc = launch_agcn_expand(x, P, Wd, bd, Wdown, bdown, zeros, zeros, ones, zeros, zdw, N, Cin, Cout, T, V, subsets, 1, st);
+            if (rc != STGCN_OK) return rc;
+            zd = zdw;
+        }
     }
     const float *mean_m = save_stats, *inv_m = save_stats + Cout, *mean_d = save_stats + 2 * Cout, *inv_d = save_stats + 3 * Cout;
     rc = launch_bn_scale_shift(bn_weight, bn_bias, mean_m, inv_m, sm_, tm_, Cout, st);
     if (rc != STGCN_OK) return rc;
-    rc = launch_bn_scale_shift(dbn_weight, dbn_bias, mean_d, inv_d, sd_, td_, Cout, st);
-    if (rc != STGCN_OK) return rc;
-    rc = launch_bn_relu_bwd_stats(zm, sm_, tm_, mean_m, inv_m, zd, sd_, td_, mean_d, inv_d, dy, sums, N, Cout, plane, st);
+    if (has_down) {
+        rc = launch_bn_scale_shift(dbn_weight, dbn_bias, mean_d, inv_d, sd_, td_, Cout, st);
+        if (rc != STGCN_OK) return rc;
+    }
+    // side b of the ReLU's argument: the second BatchNorm, or (scale == NULL) the identity residual x itself
+    const float *zb = has_down ? zd : x, *sb = has_down ? sd_ : nullptr, *tb = has_down ? td_ : nullptr;
+    const float *mb = has_down ? mean_d : nullptr, *ib = has_down ? inv_d : nullptr;
+    rc = launch_bn_relu_bwd_stats(zm, sm_, tm_, mean_m, inv_m, zb, sb, tb, mb, ib, dy, sums, N, Cout, plane, st);
     if (rc != STGCN_OK) return rc;
     rc = launch_bn_bwd_finalize(sums, 1, (double)N * plane, bn_weight, inv_m, dgamma, dbeta, coefm, Cout, st);
     if (rc != STGCN_OK) return rc;
-    rc = launch_bn_bwd_finalize(sums, 2, (double)N * plane, dbn_weight, inv_d, ddgamma, ddbeta, coefd, Cout, st);
+    if (has_down) {
+        rc = launch_bn_bwd_finalize(sums, 2, (double)N * plane, dbn_weight, inv_d, ddgamma, ddbeta, coefd, Cout, st);
+        if (rc != STGCN_OK) return rc;
+    }
+    if (fused) {
+        const float *const m_[6] = {zm, sm_, tm_, mean_m, inv_m, coefm};
+        const float *const d_[6] = {zd, sd_, td_, mean_d, inv_d, coefd};
+        return launch_agcn_bwd(x, P, A_eff, m_, d_, dy, Wa, ba, Wb, bb, Wd, (float *)body, dWa, dba, dWb, dbb, dWd, dbd, dWdown,
+                               dbdown, dPA, N, Cin, Cout, T, V, inter_c, subsets, st);
+    }
+    // generic path: materialise both pre-BatchNorm gradients, then the GEMM chain
+    float *dzm = (float *)body, *dzd = dzm + total, *gws = dzd + total;
+    rc = launch_bn_relu_bwd_apply(zm, sm_, tm_, mean_m, inv_m, zb, sb, tb, mb, ib, dy, coefm, has_down ? coefd : nullptr, dzm,
+                                  has_down ? dzd : nullptr, nullptr, N, Cout, plane, st);
     if (rc != STGCN_OK) return rc;
-    const float *const m_[6] = {zm, sm_, tm_, mean_m, inv_m, coefm};
-    const float *const d_[6] = {zd, sd_, td_, mean_d, inv_d, coefd};
-    return launch_agcn_bwd(x, P, A_eff, m_, d_, dy, Wa, ba, Wb, bb, Wd, part, dWa, dba, dWb, dbb, dWd, dbd, dWdown, dbdown,
-                           dPA, N, Cin, Cout, T, V, inter_c, subsets, st);
+    int dx_init = 0;
+    if (dx != nullptr && !has_down) {        // the "+ x" term of unit_agcn.py:57-58,92
+        hipLaunchKernelGGL(identity_residual_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, zm, x, sm_, tm_,
+                           dy, dx, total, Cout, plane);
+        STGCN_LAUNCH_CHECK("identity_residual_grad_kernel");
+        dx_init = 1;
+    }
+    return launch_agcn_bwd_generic(x, P, A_eff, dzm, has_down ? dzd : nullptr, Wa, ba, Wb, bb, Wd, Wdown, gws, dWa, dba, dWb, dbb,
+                                   dWd, dbd, dWdown, dbdown, dPA, dx, dx_init, N, Cin, Cout, T, V, inter_c, subsets, st);
 }
 
 // workspace layout (tcn): [ones C][zeros C][scale, shift][sums 2C doubles][packed weights][z N*Cout*Tout*V]

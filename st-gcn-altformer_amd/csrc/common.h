@@ -182,6 +182,34 @@ int launch_agcn_bwd(const float *x, const float *P, const float *A_eff, const fl
                     float *part, float *dWa, float *dba, float *dWb, float *dbb, float *dWd, float *dbd, float *dWdown,
                     float *dbdown, float *dPA, int N, int Cin, int Cout, int T, int V, int inter_c, int S, hipStream_t st);
 
+// strided batched fp32 GEMM + small helpers (gemm_f32.hip): C[b][m][n] (+)= alpha * sum_k A[b][m][k] B[b][k][n] (+ bias[m])
+struct GemmArgs {
+    const float *A, *B;
+    float *C;
+    const float *bias;                 // per output row m, or NULL
+    int M, N, K;
+    long long a_sm, a_sk, a_sb;        // element strides: row, contraction index, batch
+    long long b_sk, b_sn, b_sb;
+    long long c_sm, c_sn, c_sb;
+    float alpha;
+    int accumulate;                    // 0: C = ..., 1: C += ...
+};
+int launch_gemm_f32(const GemmArgs &g, int batch, hipStream_t st);
+int launch_sum_parts(const float *part, float *out, int parts, size_t n, hipStream_t st);   // fixed order p = 0, 1, ...
+int launch_add_inplace(float *dst, const float *src, size_t n, hipStream_t st);
+int launch_row_sum(const float *in, float *out, int rows, int cols, hipStream_t st);
+int launch_softmax_bwd(const float *P, const float *A_eff, const float *dP, float *dS, int N, int V, int S, int s, float alpha,
+                       hipStream_t st);
+
+// generic backward of the training-mode graph conv: any Cin / Cout / subsets, identity or conv residual, optional dx
+// (agcn_backward_generic.hip)
+size_t agcn_bwd_generic_ws_floats(int N, int Cin, int Cout, int T, int V, int inter_c, int S);
+int launch_agcn_bwd_generic(const float *x, const float *P, const float *A_eff, const float *dzm, const float *dzd,
+                            const float *Wa, const float *ba, const float *Wb, const float *bb, const float *Wd,
+                            const float *Wdown, float *ws, float *dWa, float *dba, float *dWb, float *dbb, float *dWd,
+                            float *dbd, float *dWdown, float *dbdown, float *dPA, float *dx, int dx_initialised, int N,
+                            int Cin, int Cout, int T, int V, int inter_c, int S, hipStream_t st);
+
 // fused stem
 size_t stem_prep_bytes(int Cin, int C, int K, int S, unsigned flags);
 int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, const float *bdown,

@@ -147,17 +147,20 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     };
 
     // ---- FK: features of a tile from x and the clip's attention fragments ------------------------------------
-    struct XRegs { float xa[8]; float xp[2][3]; };
+    // Work unit u = (M-block mb = u>>1, joint half hh = u&1): M-block = tile frames 4mb .. 4mb+3 (frame 0 = the first
+    // halo frame), half = joint columns 16hh .. 16hh+15.  As A operand lane l holds row (frame (l&15)>>2, channel l&3)
+    // and joints 8*(l>>4) .. +7; as accumulator it holds frame l>>4, joint column l&15.  Wave w owns units w, w+8, ...:
+    // with 21 frames x 22 joints that is 12 units, two for waves 0-3 and one for waves 4-7 — three per SIMD.
+    struct XRegs { float xa[8]; float xp[3]; };
     auto dma_pfrag = [&](int tile) {         // 12 KiB: the clip's fragments -> Pf
         const int n = tile / tiles_per_clip;
         const uint4 *src = reinterpret_cast<const uint4 *>(feat) + (size_t)n * 12 * 64 + lane;
         for (int f = wave; f < 12; f += 8) dma16(src + f * 64, pf_lds + f * FRAG);
     };
-    // M-block mb = tile frames 4mb .. 4mb+3 (frame 0 = the first halo frame); as A operand lane l holds row (frame
-    // (l&15)>>2, channel l&3) and joints 8*(l>>4) .. +7; as accumulator it holds frame l>>4, joint column l&15.
-    auto load_x = [&](XRegs &xr, int tile, int mb) {
+    auto load_x = [&](XRegs &xr, int tile, int u) {
         int lane = tid & 63;                 // opaque per call: keeps the lane-only address terms out of scratch (see epilogue)
         asm volatile("" : "+v"(lane));
+        const int mb = u >> 1, hh = u & 1;
         const int n = tile / tiles_per_clip;
         const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NPX);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -173,63 +176,66 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
             }
         }
         {
-            const int t = tf + (lane >> 4);
+            const int t = tf + (lane >> 4), w = 16 * hh + (lane & 15);
+            const bool ok = t >= 0 && t < T && w < V;
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int w = 16 * hh + (lane & 15);
-                const bool ok = t >= 0 && t < T && w < V;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const unsigned off = ok ? (unsigned)((k * xsc + (t * V + w) * xsp) * 4) : 0x7ffffff0u;
-                    xr.xp[hh][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
-                }
+            for (int k = 0; k < 3; ++k) {
+                const unsigned off = ok ? (unsigned)((k * xsc + (t * V + w) * xsp) * 4) : 0x7ffffff0u;
+                xr.xp[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
             }
         }
     };
-    auto feature_phase = [&](int tile, const XRegs &first) {
+    auto feature_unit = [&](const TileGeomB &g, int u, const XRegs &xr) {
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));
+        const int mb = u >> 1, hh = u & 1;
+        uint4 xh, xl;
+        split8(xr.xa, xh, xl);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, xh), al = __builtin_bit_cast(bf16x8, xl);
+        f32x4 d[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, Pf[((s * 2 + hh) * 2 + 0) * 64 + lane]);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, Pf[((s * 2 + hh) * 2 + 1) * 64 + lane]);
+            d[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bl, d[s], 0, 0, 0);
+            d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d[s], 0, 0, 0);
+            d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d[s], 0, 0, 0);
+            d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d[s], 0, 0, 0);
+        }
+        const int w = 16 * hh + (lane & 15);
+        const int p = (4 * mb + (lane >> 4)) * V + w;        // pixel row of the tile
+        const int gi = g.origin + p;
+        const bool valid = p < g.span && gi >= 0 && gi < TV; // else: the temporal conv's zero padding
+        const float one = valid ? 1.f : 0.f;
+        const float fa[8] = {d[0][0] * one, d[0][1] * one, d[0][2] * one, d[1][0] * one,
+                             d[1][1] * one, d[1][2] * one, d[2][0] * one, d[2][1] * one};
+        const float fb[8] = {d[2][2] * one, xr.xp[0] * one, xr.xp[1] * one, xr.xp[2] * one, one, 0.f, 0.f, 0.f};
+        uint4 ha, la, hb, lb;
+        split8(fa, ha, la);
+        split8(fb, hb, lb);
+        if (w < V && p < ROWS) {
+            Fs[p] = ha;
+            Fs[(size_t)ROWS + p] = hb;
+            Fs[(size_t)2 * ROWS + p] = la;
+            Fs[(size_t)3 * ROWS + p] = lb;
+        }
+    };
+    // units w and w+8 arrive prefetched (xa / xb); any further ones (narrow frames only) are loaded here
+    auto feature_phase = [&](int tile, const XRegs &xa, const XRegs &xb) {
         const int n = tile / tiles_per_clip;
         const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT4, 1, T, NPX);
         const int need = min(ROWS, ((g.span + 15) >> 4) << 4);       // rows the producer will read
-        const int nmb = ((need + V - 1) / V + 3) >> 2;
-        for (int mb = wave; mb < nmb; mb += 8) {
-            XRegs xr = first;
-            if (mb != wave) load_x(xr, tile, mb);                    // (narrow frames only: more than 8 M-blocks)
-            uint4 xh, xl;
-            split8(xr.xa, xh, xl);
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, xh), al = __builtin_bit_cast(bf16x8, xl);
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                if (16 * hh >= V) break;
-                f32x4 d[3];
-#pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, Pf[((s * 2 + hh) * 2 + 0) * 64 + lane]);
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, Pf[((s * 2 + hh) * 2 + 1) * 64 + lane]);
-                    d[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bl, d[s], 0, 0, 0);
-                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d[s], 0, 0, 0);
-                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d[s], 0, 0, 0);
-                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d[s], 0, 0, 0);
-                }
-                const int w = 16 * hh + (lane & 15);
-                const int p = (4 * mb + (lane >> 4)) * V + w;        // pixel row of the tile
-                const int gi = g.origin + p;
-                const bool valid = p < g.span && gi >= 0 && gi < TV; // else: the temporal conv's zero padding
-                const float one = valid ? 1.f : 0.f;
-                const float fa[8] = {d[0][0] * one, d[0][1] * one, d[0][2] * one, d[1][0] * one,
-                                     d[1][1] * one, d[1][2] * one, d[2][0] * one, d[2][1] * one};
-                const float fb[8] = {d[2][2] * one, xr.xp[hh][0] * one, xr.xp[hh][1] * one, xr.xp[hh][2] * one, one, 0.f, 0.f, 0.f};
-                uint4 ha, la, hb, lb;
-                split8(fa, ha, la);
-                split8(fb, hb, lb);
-                if (w < V && p < ROWS) {
-                    Fs[p] = ha;
-                    Fs[(size_t)ROWS + p] = hb;
-                    Fs[(size_t)2 * ROWS + p] = la;
-                    Fs[(size_t)3 * ROWS + p] = lb;
-                }
+        const int nun = (((need + V - 1) / V + 3) >> 2) * 2;         // M-blocks x 2 halves
+        const bool two = V > 16;
+        for (int u = wave; u < nun; u += 8) {
+            if (!two && (u & 1)) continue;
+            if (u == wave) feature_unit(g, u, xa);
+            else if (u == wave + 8) feature_unit(g, u, xb);
+            else {
+                XRegs xr;
+                load_x(xr, tile, u);
+                feature_unit(g, u, xr);
             }
         }
     };
@@ -293,9 +299,9 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
     }
     int tile = blockIdx.x;
     {
-        XRegs x0 = {};                        // (block scope: nothing of it stays live into the tile loop)
+        XRegs x0 = {}, x1 = {};               // (block scope: nothing of it stays live into the tile loop)
         if constexpr (FK) {
-            if (tile < ntiles) { dma_pfrag(tile); load_x(x0, tile, wave); }
+            if (tile < ntiles) { dma_pfrag(tile); load_x(x0, tile, wave); load_x(x1, tile, wave + 8); }
         } else {
             if (tile < ntiles) dma_features(tile);
         }
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         dma_wait();
         __syncthreads();                      // W12q, Fs(tile) / Pf(tile), weight stage 0 landed
         if (tile < ntiles) {
-            if constexpr (FK) feature_phase(tile, x0);
+            if constexpr (FK) feature_phase(tile, x0, x1);
             else zero_invalid_rows(tile);
         }
         __syncthreads();
@@ -437,9 +443,10 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         // (vmcnt(0)) for every store of this epilogue.
         int n_e = n, q0_e = g.q0, qlast_e = g.q_last, lane_e = lane;   // (lane too: lane-only terms are kernel invariants)
         asm volatile("" : "+s"(n_e), "+s"(q0_e), "+s"(qlast_e), "+v"(lane_e));
-        XRegs xnext;                          // (declared per tile and always fully written: dead across the loop back-edge)
+        XRegs xnext, xnext2;                  // (declared per tile and always fully written: dead across the loop back-edge)
         if constexpr (FK) {                   // next tile's x: in flight while this tile's results are stored
             load_x(xnext, min(next_tile, ntiles - 1), wave);
+            load_x(xnext2, min(next_tile, ntiles - 1), wave + 8);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!STGCN_ABL(4) && (abl & OPT_OUT_NTVC)) {
@@ -519,7 +526,11 @@ __global__ __launch_bounds__(NT4) void stem_bf16_v4_kernel(
         if (next_tile < ntiles) {
             if constexpr (FK) {               // its fragments landed at the last stage barrier, its x during the stores
                 __syncthreads();              // every wave's staging reads are done (the staging runs into Fs)
-                feature_phase(next_tile, xnext);
+                STGCN_STAMP(t_f0)
+                feature_phase(next_tile, xnext, xnext2);
+                STGCN_STAMP(t_f1)
+                STGCN_ACC(5, t_e1, t_f0)
+                STGCN_ACC(6, t_f0, t_f1)
             } else {                          // its feature rows landed at the last stage barrier
                 zero_invalid_rows(next_tile);
             }
@@ -690,10 +701,12 @@ __global__ __launch_bounds__(NT4) void tcn_bf16_v4_kernel(
         }
         // epilogue (see KF4): each 32-channel x 64-pixel block through this wave's 8 KiB staging slice, 16 B per lane
         {
+            int n_e = n, q0_e = g.q0, qlast_e = g.q_last, lane_e = lane;   // opaque copies: see KF4's epilogue
+            asm volatile("" : "+s"(n_e), "+s"(q0_e), "+s"(qlast_e), "+v"(lane_e));
             float *stg = reinterpret_cast<float *>(buf0 + wave * EPI_BYTES);
-            const int qw = g.q0 + wn * 64;
+            const int qw = q0_e + wn * 64;
             if (abl & OPT_OUT_NTVC) {
-                const int hh = lane >> 5;
+                const int hh = lane_e >> 5;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int ob = cg * 128 + (wm * 2 + m) * 32;
@@ -702,7 +715,7 @@ __global__ __launch_bounds__(NT4) void tcn_bf16_v4_kernel(
                         const float4 sh4 = *reinterpret_cast<const float4 *>(shift + ob + 8 * gq + 4 * hh);
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const int px = j * 32 + (lane & 31);
+                            const int px = j * 32 + (lane_e & 31);
                             const float4 v = make_float4(fmaxf(acc[m][j][4 * gq + 0] + sh4.x, act_lo), fmaxf(acc[m][j][4 * gq + 1] + sh4.y, act_lo),
                                                          fmaxf(acc[m][j][4 * gq + 2] + sh4.z, act_lo), fmaxf(acc[m][j][4 * gq + 3] + sh4.w, act_lo));
                             *reinterpret_cast<float4 *>(stg + px * 32 + (((2 * gq + hh) ^ (px & 7)) << 2)) = v;
@@ -710,11 +723,11 @@ __global__ __launch_bounds__(NT4) void tcn_bf16_v4_kernel(
                     }
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {
-                        const int idx = it * 64 + lane, px = idx >> 3, sl = idx & 7;
+                        const int idx = it * 64 + lane_e, px = idx >> 3, sl = idx & 7;
                         const float4 v = *reinterpret_cast<const float4 *>(stg + px * 32 + ((sl ^ (px & 7)) << 2));
                         const int q = qw + px;
-                        const size_t gidx = ((size_t)n * TV + q) * C + ob + 4 * sl;
-                        if (q <= g.q_last) {
+                        const size_t gidx = ((size_t)n_e * TV + q) * C + ob + 4 * sl;
+                        if (q <= qlast_e) {
                             if constexpr (BF16OUT)
                                 *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + gidx) =
                                     make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
@@ -729,18 +742,18 @@ __global__ __launch_bounds__(NT4) void tcn_bf16_v4_kernel(
                     const int ob = cg * 128 + (wm * 2 + m) * 32;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int cr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int cr = (r & 3) + 8 * (r >> 2) + 4 * (lane_e >> 5);
                         const float sh = shift[ob + cr];
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) stg[cr * 64 + j * 32 + (lane & 31)] = fmaxf(acc[m][j][r] + sh, act_lo);
+                        for (int j = 0; j < 2; ++j) stg[cr * 64 + j * 32 + (lane_e & 31)] = fmaxf(acc[m][j][r] + sh, act_lo);
                     }
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {
-                        const int idx = it * 64 + lane, row = idx >> 4, c4 = (idx & 15) * 4;
+                        const int idx = it * 64 + lane_e, row = idx >> 4, c4 = (idx & 15) * 4;
                         const float4 v = *reinterpret_cast<const float4 *>(stg + row * 64 + c4);
                         const int q = qw + c4;
-                        const size_t gidx = ((size_t)n * C + ob + row) * TV + q;
-                        if (q + 3 <= g.q_last && (gidx & 3) == 0) {       // 16-byte (8-byte for bf16) aligned store
+                        const size_t gidx = ((size_t)n_e * C + ob + row) * TV + q;
+                        if (q + 3 <= qlast_e && (gidx & 3) == 0) {       // 16-byte (8-byte for bf16) aligned store
                             if constexpr (BF16OUT)
                                 *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + gidx) =
                                     make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
@@ -750,7 +763,7 @@ __global__ __launch_bounds__(NT4) void tcn_bf16_v4_kernel(
                             const float e4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (q + e <= g.q_last) store_out<BF16OUT>(y, gidx + e, e4[e]);
+                                if (q + e <= qlast_e) store_out<BF16OUT>(y, gidx + e, e4[e]);
                         }
                     }
                 }

@@ -256,26 +256,35 @@ def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_
 
 
 def agcn_backward_supported(N, Cin, Cout, T, V, S) -> bool:
-    return _capi.lib().stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, S, 1) > 0
+    """Any shape the attention kernels cover (V <= 64) has a HIP backward: the fused kernel for the stem class, the GEMM
+    chain otherwise."""
+    return _capi.lib().stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, S, 3) > 0
 
 
 def agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, zm, zd, bn_weight, bn_bias, dbn_weight,
-                        dbn_bias, stats, dy):
-    """Parameter gradients of the training-mode unit_agcn forward (x is data: no dx).  zm / zd: the saved pre-BatchNorm
-    branches, or None to have them rebuilt in the call's workspace.  Returns a dict keyed dWa, dba, dWb, dbb, dWd, dbd,
-    dWdown, dbdown, dgamma, dbeta, ddgamma, ddbeta, dPA."""
+                        dbn_bias, stats, dy, need_dx=False):
+    """Gradients of the training-mode unit_agcn forward.  zm / zd: the saved pre-BatchNorm branches, or None to have
+    them rebuilt in the call's workspace.  Wdown / bdown / dbn_* None = identity residual (Cin == Cout).
+    Returns a dict keyed dWa, dba, dWb, dbb, dWd, dbd, dgamma, dbeta, dPA, plus dWdown, dbdown, ddgamma, ddbeta with a
+    down branch and dx with ``need_dx`` (the input gradient, model/ST_TR/ST_TR_new.py:355-372)."""
     dev = x.device
     N, Cin, T, V = x.shape
     S, inter_c, _ = Wa.shape
     Cout = Wd.shape[1]
-    nbytes = _capi.lib().stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, S, 1 if zm is None else 0)
+    has_down = Wdown is not None
+    # bit 1: size for the generic path whenever the call may take it (dx, identity residual, non-stem shapes)
+    nbytes = _capi.lib().stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, S, (1 if zm is None else 0) | 2)
     if nbytes == 0:
         raise NotImplementedError(f"unit_agcn backward: shape Cin={Cin} S={S} Cout={Cout} V={V} is not covered by the HIP path")
     ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
     f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
     g = dict(dWa=f(S, inter_c, Cin), dba=f(S, inter_c), dWb=f(S, inter_c, Cin), dbb=f(S, inter_c), dWd=f(S, Cout, Cin),
-             dbd=f(S, Cout), dWdown=f(Cout, Cin), dbdown=f(Cout), dgamma=f(Cout), dbeta=f(Cout), ddgamma=f(Cout),
-             ddbeta=f(Cout), dPA=f(S, V, V))
+             dbd=f(S, Cout), dgamma=f(Cout), dbeta=f(Cout), dPA=f(S, V, V))
+    if has_down:
+        g.update(dWdown=f(Cout, Cin), dbdown=f(Cout), ddgamma=f(Cout), ddbeta=f(Cout))
+    if need_dx:
+        g["dx"] = torch.empty_like(x)
+    o = lambda k: _dev_ptr(g.get(k), k)
     with torch.cuda.device(dev):
         _capi.call("stgcn_agcn_backward_train", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev), _dev_ptr(Wa, "Wa", dev),
                    _dev_ptr(ba, "ba", dev), _dev_ptr(Wb, "Wb", dev), _dev_ptr(bb, "bb", dev), _dev_ptr(Wd, "Wd", dev),
@@ -284,8 +293,8 @@ def agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, zm, z
                    _dev_ptr(bn_weight, "bn_weight", dev), _dev_ptr(bn_bias, "bn_bias", dev),
                    _dev_ptr(dbn_weight, "dbn_weight", dev), _dev_ptr(dbn_bias, "dbn_bias", dev),
                    _dev_ptr(stats, "stats", dev), _dev_ptr(dy, "dy", dev),
-                   *[_dev_ptr(g[k], k) for k in ("dWa", "dba", "dWb", "dbb", "dWd", "dbd", "dWdown", "dbdown", "dgamma",
-                                                 "dbeta", "ddgamma", "ddbeta", "dPA")],
+                   *[o(k) for k in ("dWa", "dba", "dWb", "dbb", "dWd", "dbd", "dWdown", "dbdown", "dgamma",
+                                    "dbeta", "ddgamma", "ddbeta", "dPA", "dx")],
                    c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), c_int(N), c_int(Cin), c_int(Cout), c_int(T),
                    c_int(V), c_int(inter_c), c_int(S), _stream(dev))
     return g

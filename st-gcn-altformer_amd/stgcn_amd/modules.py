@@ -154,37 +154,50 @@ class _Unit2DTrainFn(torch.autograd.Function):
 
 
 class _AgcnTrainFn(torch.autograd.Function):
-    """unit_agcn.forward in .train() with the HIP forward and backward (parameter gradients; x is data)."""
+    """unit_agcn.forward in .train() with the HIP forward and backward: every parameter gradient and, when the input
+    requires it (the deeper TCN_GCN_unit layers, model/ST_TR/ST_TR_new.py:355-372), dx."""
 
     @staticmethod
     def forward(ctx, mod, x, *params):               # `params` = mod._train_params(): graph edges only, values via _staged
         st = mod._staged(x.device)
-        bn, d = mod.bn, mod.down[1]
+        bn = mod.bn
+        has_down = mod._has_down()
+        d = mod.down[1] if has_down else None
+        xd = x.detach()
         y, P, zm, zd, stats = F.agcn_forward_train(
-            x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"], st["bdown"],
+            xd, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"], st["bdown"],
             (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var),
-            (d.weight.detach(), d.bias.detach(), d.running_mean, d.running_var), bn.momentum, bn.eps, save=True)
+            (d.weight.detach(), d.bias.detach(), d.running_mean, d.running_var) if has_down else None,
+            bn.momentum, bn.eps, save=True)
         # (zm, zd are None: the stem shape class derives its BatchNorm statistics from feature moments and writes
-        #  neither branch; the backward rebuilds them in its own workspace — nothing full-size is kept in between)
-        ctx.save_for_backward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"],
-                              st["bdown"], P, bn.weight.detach(), bn.bias.detach(), d.weight.detach(), d.bias.detach(),
-                              stats)
+        #  neither branch; the backward rebuilds what it needs in its own workspace — nothing full-size is kept in between)
+        saved = [xd, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], P, bn.weight.detach(),
+                 bn.bias.detach(), stats]
+        if has_down:
+            saved += [st["Wdown"], st["bdown"], d.weight.detach(), d.bias.detach()]
+        ctx.save_for_backward(*saved)
         ctx.S = mod.num_subset
+        ctx.has_down = has_down
         mod.last_attention = P
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, bnw, bnb, dbnw, dbnb, stats = ctx.saved_tensors
+        t = ctx.saved_tensors
+        x, A_eff, Wa, ba, Wb, bb, Wd, bd, P, bnw, bnb, stats = t[:12]
+        Wdown, bdown, dbnw, dbnb = t[12:16] if ctx.has_down else (None, None, None, None)
+        need_dx = ctx.needs_input_grad[1]
         g = F.agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, None, None, bnw, bnb, dbnw, dbnb, stats,
-                                  dy.contiguous())
+                                  dy.contiguous(), need_dx=need_dx)
         S = ctx.S
         out = [g["dPA"]]
         for w, b in (("dWa", "dba"), ("dWb", "dbb"), ("dWd", "dbd")):
             for i in range(S):
                 out += [g[w][i].unsqueeze(-1).unsqueeze(-1), g[b][i]]
-        out += [g["dWdown"].unsqueeze(-1).unsqueeze(-1), g["dbdown"], g["ddgamma"], g["ddbeta"], g["dgamma"], g["dbeta"]]
-        return (None, None, *out)
+        if ctx.has_down:
+            out += [g["dWdown"].unsqueeze(-1).unsqueeze(-1), g["dbdown"], g["ddgamma"], g["ddbeta"]]
+        out += [g["dgamma"], g["dbeta"]]
+        return (None, g.get("dx"), *out)
 
 
 def conv_init(module):
@@ -375,25 +388,26 @@ class unit_agcn(nn.Module):
         for convs in (self.conv_a, self.conv_b, self.conv_d):
             for c in convs:
                 ps += [c.weight, c.bias]
-        return ps + [self.down[0].weight, self.down[0].bias, self.down[1].weight, self.down[1].bias, self.bn.weight,
-                     self.bn.bias]
+        if self._has_down():
+            ps += [self.down[0].weight, self.down[0].bias, self.down[1].weight, self.down[1].bias]
+        return ps + [self.bn.weight, self.bn.bias]
 
     def _forward_train(self, x, st):
         """Batch-statistics BatchNorm forward (model/unit_agcn.py:91-92 with self.training); updates running buffers."""
         bn = self.bn
         if bn.momentum is None or not bn.track_running_stats:
             raise NotImplementedError("unit_agcn: training-mode BatchNorm needs momentum and running statistics")
-        if _wants_grad(self, x):                   # autograd: HIP forward + HIP backward (agcn_backward.hip)
+        if _wants_grad(self, x):                   # autograd: HIP forward + HIP backward (fused kernel or GEMM chain)
             N, C, T, V = x.shape
-            if x.requires_grad or not self._has_down() or not F.agcn_backward_supported(N, C, self.out_channels, T, V,
-                                                                                        self.num_subset):
+            if not F.agcn_backward_supported(N, C, self.out_channels, T, V, self.num_subset) \
+                    or self.inter_c > max(self.out_channels // 4, 1):
                 raise NotImplementedError(
-                    "unit_agcn: the HIP backward covers the stem's shape class (C_in = 3, 3 subsets, C_out in "
-                    "{64,128,256}, input without gradient); this call is outside it (SURVEY.md §8f rank 3)")
+                    "unit_agcn: the HIP backward covers V <= 64 joints and coff_embedding >= 4; this call is outside it")
             y = _AgcnTrainFn.apply(self, x, *self._train_params())
             with torch.no_grad():
                 bn.num_batches_tracked += 1
-                self.down[1].num_batches_tracked += 1
+                if self._has_down():
+                    self.down[1].num_batches_tracked += 1
             return y
         down_bn = None
         if self._has_down():

@@ -361,9 +361,10 @@ def test_errors_are_loud(dev):
     from stgcn_amd import Unit2D, functional as F, StgcnError
     from stgcn_amd import unit_agcn
     m = Unit2D(8, 8, kernel_size=3).to(dev)
-    g = unit_agcn(8, 8, torch.rand(3, 4, 4)).to(dev)
+    g = unit_agcn(8, 8, torch.rand(3, 4, 4), coff_embedding=2).to(dev)
     with pytest.raises(NotImplementedError):
-        g.train()(torch.zeros(1, 8, 4, 4, device=dev))   # autograd outside the shapes the HIP backward covers: refused
+        g.train()(torch.zeros(1, 8, 4, 4, device=dev))   # autograd outside what the HIP backward covers (embedding wider
+                                                         # than C_out/4): refused, not silently cut out of the graph
     with pytest.raises(RuntimeError):
         m.eval()(torch.zeros(1, 8, 4, 4))            # CPU tensor: no fallback
     with pytest.raises(ValueError):
@@ -677,8 +678,9 @@ def test_unit2d_backward_vs_oracle(cin, cout, K, stride, N, T, V, bias, math, de
 
 
 def _agcn_oracle_leaves(gp):
-    leaves = {"PA": gp.PA, "down_w": gp.down_w, "down_b": gp.down_b, "bn_w": gp.bn.weight, "bn_b": gp.bn.bias,
-              "dbn_w": gp.down_bn.weight, "dbn_b": gp.down_bn.bias}
+    leaves = {"PA": gp.PA, "bn_w": gp.bn.weight, "bn_b": gp.bn.bias}
+    if gp.down_w is not None:
+        leaves.update({"down_w": gp.down_w, "down_b": gp.down_b, "dbn_w": gp.down_bn.weight, "dbn_b": gp.down_bn.bias})
     for i in range(gp.num_subset):
         leaves.update({f"a_w{i}": gp.conv_a_w[i], f"a_b{i}": gp.conv_a_b[i], f"b_w{i}": gp.conv_b_w[i],
                        f"b_b{i}": gp.conv_b_b[i], f"d_w{i}": gp.conv_d_w[i], f"d_b{i}": gp.conv_d_b[i]})
@@ -688,9 +690,10 @@ def _agcn_oracle_leaves(gp):
 
 
 def _agcn_module_grads(gcn):
-    g = {"PA": gcn.PA.grad, "down_w": gcn.down[0].weight.grad.flatten(1), "down_b": gcn.down[0].bias.grad,
-         "bn_w": gcn.bn.weight.grad, "bn_b": gcn.bn.bias.grad, "dbn_w": gcn.down[1].weight.grad,
-         "dbn_b": gcn.down[1].bias.grad}
+    g = {"PA": gcn.PA.grad, "bn_w": gcn.bn.weight.grad, "bn_b": gcn.bn.bias.grad}
+    if gcn._has_down():
+        g.update({"down_w": gcn.down[0].weight.grad.flatten(1), "down_b": gcn.down[0].bias.grad,
+                  "dbn_w": gcn.down[1].weight.grad, "dbn_b": gcn.down[1].bias.grad})
     for i in range(gcn.num_subset):
         g.update({f"a_w{i}": gcn.conv_a[i].weight.grad.flatten(1), f"a_b{i}": gcn.conv_a[i].bias.grad,
                   f"b_w{i}": gcn.conv_b[i].weight.grad.flatten(1), f"b_b{i}": gcn.conv_b[i].bias.grad,
@@ -735,6 +738,84 @@ def test_unit_agcn_backward_vs_oracle(N, T, V, cout, dev):
     parity_gate(y.detach(), yr.detach(), 1e-4, "training-mode forward")
     (y * G.to(dev)).sum().backward()
     _compare_grads(_agcn_module_grads(gcn), ref, 1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,N,T,V,want_dx", [
+    (64, 64, 2, 12, 22, True),      # TCN_GCN_unit(64, 64): identity residual (unit_agcn.py:57-58), input gradient
+    (64, 128, 2, 10, 22, True),     # TCN_GCN_unit(64, 128): conv + BatchNorm residual, input gradient
+    (128, 256, 1, 9, 25, True),     # wider, odd joint count
+    (16, 32, 3, 7, 46, True),       # two-hand graph width, small channels (tiles mostly padding)
+    (3, 128, 2, 20, 22, True),      # the stem's own shape WITH an input gradient: the generic chain, not the fused kernel
+    (64, 128, 2, 10, 22, False)])   # generic shape, x is data
+def test_unit_agcn_generic_backward_vs_oracle(cin, cout, N, T, V, want_dx, dev):
+    """unit_agcn backward for generic C_in / C_out, identity or conv residual, INCLUDING dx — what makes
+    a TCN_GCN_unit (model/ST_TR/ST_TR_new.py:355-372) trainable.  Every gradient against autograd through the fp64
+    oracle at 1e-4 of its tensor's max."""
+    from oracle import stgcn_oracle as so
+    gcn, _, gp, _, gen = _random_stem(V, None, 2000 + cin + cout + T + V, dev, cin=cin, c=cout)
+    gp = gp.to(torch.float64)
+    leaves = _agcn_oracle_leaves(gp)
+    x = torch.randn(N, cin, T, V, generator=gen)
+    xr = x.double().requires_grad_(True)
+    yr = so.agcn_forward(xr, gp, training=True)
+    G = _kink_free_cotangent(yr, gen)
+    names = sorted(leaves)
+    grads = torch.autograd.grad((yr * G.double()).sum(), [leaves[k] for k in names] + [xr])
+    ref = dict(zip(names, grads[:-1]))
+    gcn.train()
+    xg = x.to(dev).requires_grad_(want_dx)
+    y = gcn(xg)
+    parity_gate(y.detach(), yr.detach(), 1e-4, "training-mode forward")
+    (y * G.to(dev)).sum().backward()
+    _compare_grads(_agcn_module_grads(gcn), ref, 1e-4)
+    if want_dx:
+        _grad_gate(xg.grad, grads[-1], 1e-4, "dx")
+    else:
+        assert xg.grad is None
+
+
+def test_tcn_gcn_unit_trains_end_to_end(dev):
+    """A TCN_GCN_unit as the ST-TR family builds it (gcn1 = unit_agcn(in,out), tcn1 = Unit2D(out,out,9,stride), residual
+    Unit2D(in,out,1,stride); forward relu-free sum as at ST_TR_new.py:355-372) assembled from the drop-in modules:
+    loss.backward() reaches every parameter and the block's input, and matches the fp64 oracle."""
+    from stgcn_amd import Unit2D, set_math_mode
+    from oracle import stgcn_oracle as so
+    V, cin, cout, stride = 22, 64, 128, 2
+    gcn, _, gp, _, gen = _random_stem(V, None, 3100, dev, cin=cin, c=cout)
+    torch.manual_seed(3101)
+    tcn, down = Unit2D(cout, cout, kernel_size=9, stride=stride), Unit2D(cin, cout, kernel_size=1, stride=stride)
+    for m in (tcn, down):
+        with torch.no_grad():
+            m.bn.weight.copy_(torch.rand(cout, generator=gen) + 0.5)
+            m.bn.bias.copy_(torch.randn(cout, generator=gen) * 0.2)
+        set_math_mode(m, "f32_valu")
+    tp = so.tcn_params_from_state(tcn.state_dict(), stride=stride).to(torch.float64)
+    dp = so.tcn_params_from_state(down.state_dict(), stride=stride).to(torch.float64)
+    gp = gp.to(torch.float64)
+    leaves = _agcn_oracle_leaves(gp)
+    tl = {"t_w": tp.conv_w, "t_b": tp.conv_b, "r_w": dp.conv_w, "r_b": dp.conv_b}
+    for t in tl.values():
+        t.requires_grad_(True)
+    x = torch.randn(2, cin, 21, V, generator=gen)
+    xr = x.double().requires_grad_(True)
+    yr = so.tcn_forward(so.agcn_forward(xr, gp, training=True), tp, training=True) + so.tcn_forward(xr, dp, training=True)
+    G = torch.randn(yr.shape, generator=gen)
+    names = sorted(leaves)
+    grads = torch.autograd.grad((yr * G.double()).sum(), [leaves[k] for k in names] + list(tl.values()) + [xr])
+    gcn.train(); tcn.to(dev).train(); down.to(dev).train()
+    xg = x.to(dev).requires_grad_(True)
+    y = tcn(gcn(xg)) + down(xg)
+    parity_gate(y.detach(), yr.detach(), 1e-4, "TCN_GCN_unit forward")
+    (y * G.to(dev)).sum().backward()
+    # inner ReLUs sit under the cotangent: a flipped mask bit moves a gradient by a finite amount (see the stem step test)
+    _compare_grads(_agcn_module_grads(gcn), dict(zip(names, grads[:len(names)])), 2e-3)
+    got = {"t_w": tcn.conv.weight.grad.squeeze(-1), "t_b": tcn.conv.bias.grad, "r_w": down.conv.weight.grad.squeeze(-1),
+           "r_b": down.conv.bias.grad}
+    for i, k in enumerate(tl):
+        ref = grads[len(names) + i]
+        scale = max(ref.abs().max().item(), grads[len(names) + (i & ~1)].abs().max().item())   # biases: zero under batch-stat BN
+        assert (got[k].double().cpu() - ref).abs().max().item() <= 2e-3 * scale, k
+    _grad_gate(xg.grad, grads[-1], 2e-3, "dx of the unit")
 
 
 @pytest.mark.parametrize("math", ["bf16x3", "f32_valu"])

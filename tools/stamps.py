@@ -29,12 +29,13 @@ with torch.no_grad():
     os.environ["STGCN_DBG_PTR"] = hex(buf.data_ptr())
     tcn(gcn(x)); torch.cuda.synchronize()
 t = buf.cpu().view(8, 8, 8).double()
-names = ["chunk0+bar", "stage compute", "stage barrier wait", "epilogue", "fixup+bar"]
+names = ["chunk0+bar", "stage compute", "stage barrier wait", "epilogue", "post-epilogue (bar + features + bar)"]
 tot = t[:, :, :5].sum(-1)
 print(f"math={a.math} abl={a.abl}: per-wave total stamped cycles: mean {tot.mean():.0f}")
 for i, nm in enumerate(names):
     v = t[:, :, i]
     print(f"  {nm:20s} mean {v.mean():10.0f}  ({100 * v.mean() / tot.mean():5.1f} %)  min {v.min():10.0f} max {v.max():10.0f}")
+print(f"  of the post-epilogue part: barrier wait behind the epilogue {t[:, :, 5].mean():.0f}, feature phase {t[:, :, 6].mean():.0f}")
 print("per-wave (workgroup 0): stage compute / barrier wait")
 for w in range(8):
-    print(f"  wave {w}: compute {t[0, w, 1]:10.0f}  wait {t[0, w, 2]:10.0f}  epilogue {t[0, w, 3]:8.0f}")
+    print(f"  wave {w}: compute {t[0, w, 1]:10.0f}  wait {t[0, w, 2]:10.0f}  epilogue {t[0, w, 3]:8.0f}  post-epi bar {t[0, w, 5]:8.0f}  features {t[0, w, 6]:8.0f}  chunk0 {t[0, w, 0]:8.0f}")

@@ -77,6 +77,33 @@ def tcn_bwd_case(name, cin, cout, K, stride, N, T, V, seed):
     print("wrote", name)
 
 
+def gcn_bwd_case(name, graph, cin, cout, N, T, seed):
+    """unit_agcn(cin, cout) alone, as the deeper TCN_GCN_unit layers use it (model/ST_TR/ST_TR_new.py:355-372): the
+    input requires a gradient; cin == cout gives the identity residual (unit_agcn.py:57-58)."""
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    A_arg = mg.spatial_A(graph)
+    gcn = mg.unit_agcn(cin, cout, A_arg)
+    mg.randomise_gcn(gcn, g, A_arg.clone())
+    V = A_arg.shape[-1]
+    x = torch.randn(N, cin, T, V, generator=g).requires_grad_(True)
+    out = {"x": x.detach().numpy(), "A_fixed": gcn.A.numpy().copy()}
+    out.update(mg.sd_np(gcn, "gcn."))
+    gcn.train()
+    with mg.cuda_is_identity():
+        y = gcn(x)
+    G = cotangent(y, g)
+    (y * G).sum().backward()
+    out["y"] = y.detach().numpy()
+    out["G"] = G.numpy()
+    out["grad.x"] = x.grad.numpy()
+    out.update(grads_np(gcn, "gcn."))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)
+
+
 if __name__ == "__main__":
+    gcn_bwd_case("bwd_gcn_shre_64_64_identity", "graph.SHRE", 64, 64, N=2, T=12, seed=43)
+    gcn_bwd_case("bwd_gcn_shre_64_128", "graph.SHRE", 64, 128, N=2, T=12, seed=44)
     stem_bwd_case("bwd_stem_shre_T20", "graph.SHRE", N=2, T=20, seed=41)
     tcn_bwd_case("bwd_tcn_64_128_k9_s2", 64, 128, 9, 2, N=2, T=21, V=22, seed=42)

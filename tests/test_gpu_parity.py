@@ -892,6 +892,19 @@ def test_stem_backward_vs_reference_gradients(math, dev):
     _check_grads_vs_golden({"gcn.": gcn, "tcn.": tcn}, g, 1e-3)     # (inner ReLU kinks, see test_stem_training_step_vs_oracle)
 
 
+@pytest.mark.parametrize("case,cin,cout", [("bwd_gcn_shre_64_64_identity", 64, 64), ("bwd_gcn_shre_64_128", 64, 128)])
+def test_generic_unit_agcn_backward_vs_reference_gradients(case, cin, cout, dev):
+    """unit_agcn(64,64) (identity residual) and unit_agcn(64,128) with x.requires_grad: parameter gradients AND dx against
+    the gradients the REFERENCE's own module produced (tests/golden/make_golden_bwd.py::gcn_bwd_case)."""
+    g = load_golden(case)
+    gcn = build_gcn(g, cin, cout, dev).train()
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+    y = gcn(x)
+    parity_gate(y.detach(), g["y"], 1e-4, "train-mode forward")
+    y.backward(torch.from_numpy(g["G"]).to(dev))
+    _check_grads_vs_golden({"gcn.": gcn}, g, 1e-4, extra={"x": x.grad})
+
+
 @pytest.mark.parametrize("math", ["bf16x3", "f32_valu"])
 def test_strided_unit2d_backward_vs_reference_gradients(math, dev):
     from stgcn_amd import set_math_mode

@@ -62,6 +62,8 @@ typedef enum {
  *                   `'b c f p -> (b p) f c'` (model_TS.py:161) then are views, not copies. */
 #define STGCN_IN_NTVC 0x40u
 #define STGCN_OUT_NTVC 0x80u
+/* stgcn_patch_embed: rows ordered (clip, joint, frame) — model_TS.py:161 — instead of (clip, frame, joint) */
+#define STGCN_EMBED_TS 0x100u
 
 int stgcn_version(void);
 const char *stgcn_last_error(void);
@@ -226,6 +228,19 @@ int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, con
                              const float *dy, float *dx, float *dW, float *dbias, float *dgamma,
                              float *dbeta, void *ws, size_t ws_bytes, int N, int Cin, int Cout, int T,
                              int V, int K, int stride, unsigned flags, void *stream);
+
+/* ---- first patch embedding of the transformer heads, on the stem's output -----------------------------
+ * What the callers do next with z = tcn0(gcn0(x)):
+ *   ST head: rearrange 'b c f p -> (b f) p c', Spatial_patch_to_embedding = nn.Linear(C, E), += Spatial_pos_embed
+ *            (model/AltFormer/model_ST.py:101-103,152-155)                      -> out ((N*T), V, E)
+ *   TS head: rearrange 'b c f p -> (b p) f c', temporal_patch_to_embedding = nn.Linear(C, E), += Temporal_pos_embed
+ *            (model/AltFormer/model_TS.py:110-111,161-163; STGCN_EMBED_TS)      -> out ((N*V), T, E)
+ * as ONE strided GEMM per clip: the rearrange is the addressing of the product, no copy of z is made.
+ * z: (N,C,T,V), or (N,T,V,C) with STGCN_IN_NTVC (what stgcn_stem_* writes with STGCN_OUT_NTVC);
+ * W (E,C) = Linear.weight, b (E) = Linear.bias, pos: (V,E) [ST] / (T,E) [TS] or NULL.  fp32 throughout (exact fp32
+ * matrix-core arithmetic).  out fp32, dense. */
+int stgcn_patch_embed(const float *z, const float *W, const float *b, const float *pos, float *out, int N, int C,
+                      int E, int T, int V, unsigned flags, void *stream);
 
 /* ---- data-parallel harness -------------------------------------------------------------------
  * Per-rank reductions that the ranks all-reduce once per step — the data-parallel form of the

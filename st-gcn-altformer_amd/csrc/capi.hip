@@ -612,6 +612,15 @@ int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, con
     return launch_tcn_wgrad(dz, x, dW, part, N, Cin, Cout, T, V, K, stride, Tout, flags, st);
 }
 
+int stgcn_patch_embed(const float *z, const float *W, const float *b, const float *pos, float *out, int N, int C, int E,
+                      int T, int V, unsigned flags, void *stream) {
+    REQUIRE_PTR(z); REQUIRE_PTR(W); REQUIRE_PTR(b); REQUIRE_PTR(out);
+    REQUIRE_POS(N); REQUIRE_POS(C); REQUIRE_POS(E); REQUIRE_POS(T); REQUIRE_POS(V);
+    if (flags & ~(STGCN_IN_NTVC | STGCN_EMBED_TS)) return fail(STGCN_ERR_ARG, "patch_embed: unknown flag bits 0x%x", flags);
+    if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "patch_embed: N=%d > 65535 clips per call", N);
+    return launch_patch_embed(z, W, b, pos, out, N, C, E, T, V, flags, (hipStream_t)stream);
+}
+
 int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int C, long plane, float n_local,
                      const float *logits, const long long *labels, long long *pred, int n_logits, int classes,
                      void *stream) {

@@ -193,6 +193,14 @@ struct GemmArgs {
     long long c_sm, c_sn, c_sb;
     float alpha;
     int accumulate;                    // 0: C = ..., 1: C += ...
+    // optional two-level ROW index: row i = q*m_inner + r addresses A at q*a_sm + r*a_sm2 and C at q*c_sm + r*c_sm2
+    // (m_inner = 0: single level, i*a_sm / i*c_sm).  nbias (optional): per column n.  cbias (optional) adds
+    // cbias[q*cb_sq + r*cb_sr + n*cb_sn].
+    int m_inner = 0;
+    long long a_sm2 = 0, c_sm2 = 0;
+    const float *nbias = nullptr;
+    const float *cbias = nullptr;
+    long long cb_sq = 0, cb_sr = 0, cb_sn = 0;
 };
 int launch_gemm_f32(const GemmArgs &g, int batch, hipStream_t st);
 int launch_sum_parts(const float *part, float *out, int parts, size_t n, hipStream_t st);   // fixed order p = 0, 1, ...
@@ -200,6 +208,10 @@ int launch_add_inplace(float *dst, const float *src, size_t n, hipStream_t st);
 int launch_row_sum(const float *in, float *out, int rows, int cols, hipStream_t st);
 int launch_softmax_bwd(const float *P, const float *A_eff, const float *dP, float *dS, int N, int V, int S, int s, float alpha,
                        hipStream_t st);
+
+// first patch embedding of the transformer heads on the stem output (gemm_f32.hip: one strided GEMM per clip)
+int launch_patch_embed(const float *z, const float *W, const float *b, const float *pos, float *out, int N, int C, int E,
+                       int T, int V, unsigned flags, hipStream_t st);
 
 // generic backward of the training-mode graph conv: any Cin / Cout / subsets, identity or conv residual, optional dx
 // (agcn_backward_generic.hip)

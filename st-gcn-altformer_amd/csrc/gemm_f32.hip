@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             const int e = tid + i * 256;
             const int m = a_k_fast ? e / GK : e % GT, k = a_k_fast ? e % GK : e / GT;
             const int gm = m0 + m, gk = k0 + k;
-            As[m * APAD + k] = (gm < g.M && gk < g.K) ? A[(size_t)gm * g.a_sm + (size_t)gk * g.a_sk] : 0.f;
+            const int q = g.m_inner ? gm / g.m_inner : gm, r = g.m_inner ? gm - q * g.m_inner : 0;
+            As[m * APAD + k] = (gm < g.M && gk < g.K) ? A[(size_t)q * g.a_sm + (size_t)r * g.a_sm2 + (size_t)gk * g.a_sk] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < GT * GK / 256; ++i) {
@@ -63,13 +64,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
     // D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
     const int gn = n0 + wn * 32 + (lane & 31);
+    const float nb = (g.nbias && gn < g.N) ? g.nbias[gn] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (gm < g.M && gn < g.N) {
-            float v = g.alpha * acc[r];
+            const int cq = g.m_inner ? gm / g.m_inner : gm, cr = g.m_inner ? gm - cq * g.m_inner : 0;
+            float v = g.alpha * acc[r] + nb;
             if (g.bias) v += g.bias[gm];
-            float *c = C + (size_t)gm * g.c_sm + (size_t)gn * g.c_sn;
+            if (g.cbias) v += g.cbias[(size_t)cq * g.cb_sq + (size_t)cr * g.cb_sr + (size_t)gn * g.cb_sn];
+            float *c = C + (size_t)cq * g.c_sm + (size_t)cr * g.c_sm2 + (size_t)gn * g.c_sn;
             *c = g.accumulate ? *c + v : v;
         }
     }
@@ -136,6 +140,31 @@ int launch_gemm_f32(const GemmArgs &g, int batch, hipStream_t st) {
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(g.M, GT), ceil_div(g.N, GT), batch), dim3(256), 0, st, g);
     STGCN_LAUNCH_CHECK("gemm_f32_kernel");
     return STGCN_OK;
+}
+
+// out[(n,t)][v][e] (model_ST.py:152-155) or out[(n,v)][t][e] (STGCN_EMBED_TS, model_TS.py:161-163)
+//   = sum_c z[n][c][t][v] W[e][c] + b[e] (+ pos[v][e] / pos[t][e]):  per clip  C[row = (t,v)][col = e] = z[n]^T . W^T
+// (pixels on the rows so that the lanes of a store run along e, the contiguous index of the output)
+int launch_patch_embed(const float *z, const float *W, const float *b, const float *pos, float *out, int N, int C, int E,
+                       int T, int V, unsigned flags, hipStream_t st) {
+    const long long P = (long long)T * V;
+    const bool ntvc = (flags & STGCN_IN_NTVC) != 0, ts = (flags & STGCN_EMBED_TS) != 0;
+    GemmArgs g{};
+    g.m_inner = V;                                   // row (t,v): q = t, r = v
+    g.A = z; g.a_sb = (long long)C * P;
+    if (ntvc) { g.a_sm = (long long)V * C; g.a_sm2 = C; g.a_sk = 1; }
+    else { g.a_sm = V; g.a_sm2 = 1; g.a_sk = P; }
+    g.B = W; g.b_sk = 1; g.b_sn = C; g.b_sb = 0;    // B[k = c][n = e] = W[e][c]
+    g.C = out; g.c_sn = 1; g.c_sb = P * E;
+    if (ts) { g.c_sm = E; g.c_sm2 = (long long)T * E; }         // output row (v, t)
+    else { g.c_sm = (long long)V * E; g.c_sm2 = E; }            // output row (t, v)
+    g.bias = nullptr;
+    g.nbias = b;
+    g.cbias = pos; g.cb_sn = 1;
+    if (ts) g.cb_sq = E; else g.cb_sr = E;
+    g.M = (int)P; g.N = E; g.K = C;
+    g.alpha = 1.f; g.accumulate = 0;
+    return launch_gemm_f32(g, N, st);
 }
 
 int launch_sum_parts(const float *part, float *out, int parts, size_t n, hipStream_t st) {

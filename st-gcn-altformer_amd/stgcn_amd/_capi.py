@@ -24,6 +24,7 @@ OUT_BF16 = 0x10
 RAW = 0x20
 IN_NTVC = 0x40    # stem entry points: x is (N,T,V,Cin)
 OUT_NTVC = 0x80   # stem entry points: out is (N,T,V,C)
+EMBED_TS = 0x100  # stgcn_patch_embed: rows ordered (clip, joint, frame)
 
 STATUS = {0: "STGCN_OK", -1: "STGCN_ERR_ARG", -2: "STGCN_ERR_UNSUPPORTED",
           -3: "STGCN_ERR_WORKSPACE", -4: "STGCN_ERR_HIP"}
@@ -49,6 +50,7 @@ PROTOTYPES = {
     "stgcn_stem_attention": (c_int, [_P] * 7 + [c_size_t] + [c_int] * 8 + [c_uint, _P]),
     "stgcn_stem_tail_prepared": (c_int, [_P] * 2 + [c_size_t] + [_P] * 3 + [c_int] * 7 + [c_uint, _P]),
     "stgcn_stem_forward_prepared": (c_int, [_P] * 9 + [c_size_t] + [_P] + [c_int] * 8 + [c_uint, _P]),
+    "stgcn_patch_embed": (c_int, [_P] * 5 + [c_int] * 5 + [c_uint, _P]),
     "stgcn_step_stats": (c_int, [_P, c_int, _P, c_int, c_int, c_long, c_float, _P, _P, _P, c_int, c_int, _P]),
     "stgcn_agcn_train_ws_bytes": (c_size_t, [c_int] * 7),
     "stgcn_agcn_forward_train": (c_int, [_P] * 18 + [c_float, c_float, _P, _P, c_size_t] + [_P] * 4 + [c_int] * 7 + [_P]),

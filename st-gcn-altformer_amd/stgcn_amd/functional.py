@@ -350,6 +350,41 @@ def tcn_backward_train(x, W, z, bn_weight, bn_bias, mean, invstd, dy, stride=1, 
     return dx, dW, dbias, dgamma, dbeta
 
 
+def patch_embed(z, weight, bias, pos=None, order="ST"):
+    """First patch embedding of the transformer heads applied to the stem output z (N,C,T,V) — contiguous, or
+    channels-last strided as the fused stem writes it with ``set_output_layout(..., "channels_last")``:
+
+      order "ST": ``rearrange(z,'b c f p -> (b f) p c')`` -> ``nn.Linear(C,E)`` -> ``+= Spatial_pos_embed``
+                  (model/AltFormer/model_ST.py:152-155)  -> (N*T, V, E)
+      order "TS": ``rearrange(z,'b c f p -> (b p) f c')`` -> ``nn.Linear(C,E)`` -> ``+= Temporal_pos_embed``
+                  (model/AltFormer/model_TS.py:161-163)  -> (N*V, T, E)
+
+    One strided GEMM per clip (stgcn_patch_embed): the rearrange is folded into the addressing.  ``weight`` (E,C),
+    ``bias`` (E), ``pos`` (1,V,E) / (1,T,E) or None."""
+    dev = z.device
+    N, C, T, V = z.shape
+    E = weight.shape[0]
+    fl = 0
+    if _is_channels_last(z):
+        fl |= _capi.IN_NTVC
+        z = z.permute(0, 2, 3, 1)
+    if order == "TS":
+        fl |= _capi.EMBED_TS
+    elif order != "ST":
+        raise ValueError(f"order must be 'ST' or 'TS' (got {order!r})")
+    if pos is not None:
+        want = (T if order == "TS" else V) * E
+        if pos.numel() != want:
+            raise ValueError(f"pos has {pos.numel()} elements, expected {want}")
+        pos = pos.reshape(-1, E)
+    out = torch.empty((N * V, T, E) if order == "TS" else (N * T, V, E), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _capi.call("stgcn_patch_embed", _dev_ptr(z, "z", dev), _dev_ptr(weight, "weight", dev), _dev_ptr(bias, "bias", dev),
+                   _dev_ptr(pos, "pos", dev), _dev_ptr(out, "out"), c_int(N), c_int(C), c_int(E), c_int(T), c_int(V),
+                   c_uint(fl), _stream(dev))
+    return out
+
+
 class KernelTimer:
     """HIP-event bracket around individual kernel launches on the launching stream.
 

@@ -124,6 +124,24 @@ def main():
             out["z_clip0"] = zn[0, :, :12].copy()              # one dense corner for a direct look
         else:
             assert np.array_equal(out["skeleton"], skel.numpy())
+        # first patch embedding of this head on the reference stem output (SURVEY §8f-1 third clause): the reference's own
+        # rearrange + nn.Linear + position embedding (model_ST.py:152-155 / model_TS.py:161-163).  The position embedding
+        # is zeros at construction: a seeded random one makes the term visible (the logits above were taken before).
+        from einops import rearrange
+        head = model.modelA if style == "ST" else model.modelB
+        lin = head.Spatial_patch_to_embedding if style == "ST" else head.temporal_patch_to_embedding
+        ge = torch.Generator().manual_seed(STEM_SEED + (1 if style == "ST" else 2))
+        pos = torch.randn((1, V, 256) if style == "ST" else (1, T, 256), generator=ge) * 0.05
+        with torch.no_grad():
+            e = lin(rearrange(z, "b c f p -> (b f) p c" if style == "ST" else "b c f p -> (b p) f c")) + pos
+        en = e.numpy()
+        out[f"emb_{style}.weight"], out[f"emb_{style}.bias"] = lin.weight.detach().numpy(), lin.bias.detach().numpy()
+        out[f"emb_{style}.pos"] = pos.numpy()
+        eidx = mg.sample_idx(en.size, 60000, STEM_SEED + 5)
+        out[f"emb_{style}_idx"], out[f"emb_{style}_val"] = eidx, en.reshape(-1)[eidx]
+        out[f"emb_{style}_absmax"] = np.abs(en).max()
+        out[f"emb_{style}_sum"] = en.astype(np.float64).sum()
+        out[f"emb_{style}_shape"] = np.array(en.shape, dtype=np.int64)
         ln = logits.numpy()
         out[f"logits_{style}"] = ln
         out[f"argmax_{style}"] = ln.argmax(1).astype(np.int64)

@@ -301,6 +301,36 @@ def test_whole_model_stem_output_and_argmax_handoff(math, dev):
         pass                                                              # read-only checkout: the gate above still ran
 
 
+@pytest.mark.parametrize("layout", ["contiguous", "channels_last"])
+@pytest.mark.parametrize("order", ["ST", "TS"])
+def test_patch_embedding_vs_reference(order, layout, dev):
+    """SURVEY §8(f)-1, third clause: rearrange + first nn.Linear(128->256) + position embedding of the transformer heads
+    (model_ST.py:152-155 / model_TS.py:161-163) as ONE entry point on the stem output, against the reference's own
+    rearrange / nn.Linear applied to the reference's stem output (fixture model_altformer_shre)."""
+    from stgcn_amd import enable_stem_fusion, functional as F, set_output_layout
+    g = load_golden("model_altformer_shre")
+    gcn = build_gcn(g, 3, 128, dev)
+    tcn = build_tcn(g, 128, 128, 9, 1, True, dev, "bf16x3")
+    enable_stem_fusion(gcn, tcn)
+    set_output_layout(tcn, layout)
+    x = torch.from_numpy(g["skeleton"]).to(dev).permute(0, 3, 1, 2)
+    W, b, pos = (torch.from_numpy(g[f"emb_{order}.{k}"]).to(dev) for k in ("weight", "bias", "pos"))
+    with torch.no_grad():
+        z = tcn(gcn(x))
+        assert z.is_contiguous() == (layout == "contiguous")
+        e = F.patch_embed(z, W, b, pos, order=order)
+        ref_torch = torch.nn.functional.linear(z.permute(0, 2, 3, 1).reshape(-1, 22, 128) if order == "ST"
+                                               else z.permute(0, 3, 2, 1).reshape(-1, 180, 128), W, b) + pos
+    assert tuple(e.shape) == tuple(g[f"emb_{order}_shape"])
+    scale = float(g[f"emb_{order}_absmax"])
+    err = (gather_flat(e.cpu(), g[f"emb_{order}_idx"]).double() - torch.from_numpy(g[f"emb_{order}_val"]).double()).abs().max().item()
+    assert err <= 1e-4 * scale, f"patch embedding {order}: {err:.3e} vs {scale:.3e}"
+    assert float(e.double().sum()) == pytest.approx(float(g[f"emb_{order}_sum"]), rel=1e-4, abs=1e-3 * scale)
+    parity_gate(e, ref_torch, 1e-5, "entry point vs torch ops on the same z", strict=False)   # same z: only fp32 reassociation
+    e0 = F.patch_embed(z, W, b, None, order=order)                      # without the position embedding
+    parity_gate(e0, ref_torch - pos, 1e-5, "no pos", strict=False)
+
+
 def test_fused_stem_result_cannot_be_misused(dev):
     """With stem fusion gcn0 returns tcn0's result typed FusedStemOutput: only the paired Unit2D can take it; a forward
     hook / residual / cast on gcn0's return value fails loudly instead of reading the wrong activation (VERDICT r1 #12)."""

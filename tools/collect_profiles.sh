@@ -1,9 +1,10 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun) from the repo root: rocprofv3 kernel-trace stats and PMC passes of the
 # default bench command; raw CSVs go to gpurun_out/prof_<tag>/, summaries are made by summarize_profiles.py.
-#   gpurun -- 'bash tools/collect_profiles.sh r01 [extra bench args]'
+#   gpurun -- 'bash tools/collect_profiles.sh r02 [extra bench args]'
+# (rocprofv3 gets the program itself after `--`: python3 bench.py …, never a wrapper; counters in their own passes)
 set -o pipefail
-TAG=${1:-r01}; shift
+TAG=${1:-r02}; shift
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}/gpurun_out/prof_$TAG
 mkdir -p "$R"

@@ -130,6 +130,11 @@ bool stem_v4_features_in_kernel(int C, int T, int V, int K, unsigned flags);
 int launch_stem_v4(const float *x, bool x_ntvc, const float *feat, const void *prep_w12, const void *Wp, const float *shift,
                    void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st);  // honours STGCN_OUT_NTVC
 
+// the same tile with one wave per SIMD (stem_bf16_v5.hip): 256 threads, a wave owns all 128 channels of 64 pixels
+bool stem_v5_supported(int C, int T, int V, int K, unsigned flags);
+int launch_stem_v5(const float *x, bool x_ntvc, const void *pfrag, const void *prep_w12, const void *Wp, const float *shift,
+                   void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st);
+
 // stand-alone temporal conv in the large-tile persistent form (stem_bf16_v4.hip): K = 9, stride 1, Cout % 128 == 0
 bool tcn_v4_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
 int launch_tcn_v4(const float *x, const void *Wp, const float *shift, void *y, int N, int Cin, int Cout, int T, int V, int K,

@@ -75,7 +75,15 @@ template <int PB, int TERMS, bool BF16OUT>
 __global__ __launch_bounds__(NT5) void stem_bf16_v5_kernel(
     const uint4 *__restrict__ pfrag, const float *__restrict__ x, int xsc, int xsp, const float *__restrict__ W12,
     const uint4 *__restrict__ Wp, const float *__restrict__ shift, void *y, int C, int T, int V, int ROWS,
-    int tiles_per_clip, int ntiles, int abl) {
+    int tiles_per_clip, int ntiles, int abl, unsigned long long *dbg) {
+#ifdef STGCN_ABLATION  // in-kernel cycle stamps (diagnostic builds only; dbg == NULL otherwise)
+#define V5_STAMP(var) unsigned long long var = 0; if (dbg) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); }
+#define V5_ACC(slot, a, b) if (dbg) { tsum[slot] += (b) - (a); }
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+#define V5_STAMP(var)
+#define V5_ACC(slot, a, b)
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem5[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -263,6 +271,7 @@ __global__ __launch_bounds__(NT5) void stem_bf16_v5_kernel(
         const int nblk = (g.span + 15) >> 4;
         const int next_tile = tile + gridDim.x;
 
+        V5_STAMP(t_0)
         // chunk 0 of this tile
         for (int b = wave; b < nblk; b += 4) {
             Prod pr;
@@ -286,6 +295,8 @@ __global__ __launch_bounds__(NT5) void stem_bf16_v5_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
         __syncthreads();                      // chunk 0 visible
+        V5_STAMP(t_1)
+        V5_ACC(0, t_0, t_1)
 
         // One tap of one wave = 8*TERMS MFMAs.  With a single wave on the SIMD nothing else covers a clump of LDS reads or
         // producer arithmetic between two MFMAs — the matrix pipe just drains — so the tap is written as SLOTS: one MFMA
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(NT5) void stem_bf16_v5_kernel(
         //               each channel block one block ahead of its use (the first two are read in front of slot 0)
         //   slots 6-13  next tap's weight fragments, slots 14-17 next tap's activation fragments
         //   slot 11     the producer's two small MFMAs, slots 14-21 its ReLU / split arithmetic, slots 22-23 its stores
-        //   slots 18-23 at a stage start: the six LDS-DMAs of the next weight stage
+        //   slots 18-23 first tap of a stage: the six loads of the next weight stage; second tap: their LDS stores
         constexpr int NM = 8 * TERMS;
         unsigned boff[KT5][2];                // LDS offsets of this wave's activation fragments (tap, pixel block)
 #pragma unroll
@@ -320,6 +331,14 @@ __global__ __launch_bounds__(NT5) void stem_bf16_v5_kernel(
                 const char *aslot = ring + (gs & 1) * STAGE5 + lane * 16;
                 a_cur.hi[0] = rd(aslot);         // this stage's first weight fragments: published by the barrier just passed
                 if constexpr (TERMS == 3) a_cur.lo[0] = rd(aslot + FRAG5);
+                // Next weight stage -> the other ring slot THROUGH REGISTERS: six 16-byte loads per lane in the first tap
+                // (from L2: each fragment is fetched once per workgroup), six ds_write_b128 in the second.  LDS-DMA costs
+                // the issuing wave 100-185 cycles per 1-KiB piece inside a busy phase (MI355X_MICROARCH.md) — six pieces per
+                // stage are 20 % of a tile when no second wave on the SIMD covers them; with 512 VGPRs per wave the 24
+                // staging registers are free.
+                uint4 wr0, wr1, wr2, wr3, wr4, wr5;   // (named scalars: an array captured by the nested lambdas went to scratch)
+                const uint4 *wnext = wsrc + (size_t)(((gs + 1) % nstage) * STG5) * 128;
+                char *wdst = ring + ((gs + 1) & 1) * STAGE5 + wave * 2 * FRAG5 + lane * 16;
                 static_for5<0, STG5>([&](auto tt_c) {
                     constexpr int tt = decltype(tt_c)::value;
                     constexpr int tap = st * STG5 + tt;
@@ -363,11 +382,16 @@ __global__ __launch_bounds__(NT5) void stem_bf16_v5_kernel(
                         if constexpr (prod && TERMS == 3 && v == 19) { pv2 -= bf16_lo_to_f32(ph1); pv3 -= bf16_hi_to_f32(ph1); }
                         if constexpr (prod && TERMS == 3 && v == 20) { ph0 = pack_bf16x2(pv0, pv1); ph1 = pack_bf16x2(pv2, pv3); }
                         if constexpr (prod && TERMS == 3 && v == 21) *reinterpret_cast<uint2 *>(nxt + img_bytes + poff) = make_uint2(ph0, ph1);
-                        if constexpr (tt == 0 && v >= 18) {             // next weight stage -> other ring slot, one DMA per filler
+                        if constexpr (tt == 0 && v >= 18) {             // next weight stage: loads (tap t, image f)
                             constexpr int d = v - 18, t = d / 2, f = d % 2;
-                            const int gsm = (gs + 1) % nstage;
-                            dma16v5(wsrc + (size_t)(gsm * STG5 + t) * 128 + f * 64,
-                                    ring_lds + ((gs + 1) & 1) * STAGE5 + (wave * 2 + f) * FRAG5 + t * 8 * FRAG5);
+                            const uint4 wv = wnext[t * 128 + f * 64];
+                            if constexpr (d == 0) wr0 = wv; else if constexpr (d == 1) wr1 = wv; else if constexpr (d == 2) wr2 = wv;
+                            else if constexpr (d == 3) wr3 = wv; else if constexpr (d == 4) wr4 = wv; else wr5 = wv;
+                        }
+                        if constexpr (tt == 1 && v >= 18) {             // ... and their LDS stores, one tap later
+                            constexpr int d = v - 18, t = d / 2, f = d % 2;
+                            const uint4 wv = d == 0 ? wr0 : d == 1 ? wr1 : d == 2 ? wr2 : d == 3 ? wr3 : d == 4 ? wr4 : wr5;
+                            *reinterpret_cast<uint4 *>(wdst + f * FRAG5 + t * 8 * FRAG5) = wv;
                         }
                     };
                     static_for5<0, NM>([&](auto i_c) {
@@ -379,28 +403,37 @@ __global__ __launch_bounds__(NT5) void stem_bf16_v5_kernel(
                     a_cur = a_nxt;
                     b_cur = b_nxt;
                 });
-                dma_wait5();
-                __syncthreads();              // stage done: next weights landed and visible; chunk boundary at st == 2
+                V5_STAMP(t_s1)
+                if constexpr (LAST) dma_wait5();   // (the next tile's attention fragments travel by LDS-DMA)
+                __syncthreads();              // stage done: next weights stored and visible; chunk boundary at st == 2
+                V5_STAMP(t_s2)
+                V5_ACC(2, t_s1, t_s2)
                 ++gs;
             });
         };
         for (int ch = 0; ch + 1 < nch; ++ch) chunk(std::false_type{}, ch);
         if (next_tile < ntiles) dma_pfrag(next_tile);                  // Pf is idle after the tile's feature phase
         chunk(std::true_type{}, nch - 1);
+        V5_STAMP(t_2)
+        V5_ACC(1, t_1, t_2)
 
         // ---- epilogue: each 32-channel x 64-pixel block through this wave's 8 KiB staging slice, 16 B per lane ------
-        // (opaque copies of the tile's scalars and of the lane: see stem_bf16_v4.hip)
-        int n_e = n, q0_e = g.q0, qlast_e = g.q_last, lane_e = lane;
-        asm volatile("" : "+s"(n_e), "+s"(q0_e), "+s"(qlast_e), "+v"(lane_e));
+        // Store addresses = a per-(tile, block, store) SCALAR base + one per-lane term that never changes: a full tile
+        // (15 of 16) takes the branch-free path where a store costs no vector arithmetic at all; the last tile of a clip
+        // keeps the per-lane bounds checks.  (With 64-bit per-lane index arithmetic and a predicate per store the tail of
+        // a tile executed ~3,800 vector instructions per wave — ~15 % of the tile with no second wave to hide it.)
         XRegs xn0, xn1, xn2;                  // next tile's x: in flight while this tile's results are stored
         load_x(xn0, min(next_tile, ntiles - 1), wave);
         load_x(xn1, min(next_tile, ntiles - 1), wave + 4);
         load_x(xn2, min(next_tile, ntiles - 1), wave + 8);
         __builtin_amdgcn_sched_barrier(0);
         float *stg = reinterpret_cast<float *>(buf0 + wave * EPI5);
-        const int qw = q0_e + wave * 64;
+        const int qw = g.q0 + wave * 64;
+        const bool full = g.q0 + NP5 - 1 <= g.q_last;            // (scalar) every pixel of the tile lies inside the clip
         if (abl & OPT_OUT_NTVC) {
-            const int hh = lane_e >> 5;
+            const int hh = lane >> 5;
+            // element offset of (pixel px = idx>>3, 4-channel slot sl = idx&7) for idx = it*64 + lane: (it*8 + lane>>3)*C + 4*(lane&7)
+            const unsigned lterm = (unsigned)((lane >> 3) * C + 4 * (lane & 7));
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int ob = cg * 128 + m * 32;
@@ -409,64 +442,78 @@ __global__ __launch_bounds__(NT5) void stem_bf16_v5_kernel(
                     const float4 sh4 = *reinterpret_cast<const float4 *>(shift + ob + 8 * gq + 4 * hh);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const int px = j * 32 + (lane_e & 31);
+                        const int px = j * 32 + (lane & 31);
                         const float4 v = make_float4(fmaxf(acc[m][j][4 * gq + 0] + sh4.x, 0.f), fmaxf(acc[m][j][4 * gq + 1] + sh4.y, 0.f),
                                                      fmaxf(acc[m][j][4 * gq + 2] + sh4.z, 0.f), fmaxf(acc[m][j][4 * gq + 3] + sh4.w, 0.f));
                         *reinterpret_cast<float4 *>(stg + px * 32 + (((2 * gq + hh) ^ (px & 7)) << 2)) = v;
                     }
                 }
+                const size_t tbase = ((size_t)n * TV + qw) * C + ob;      // scalar
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
-                    const int idx = it * 64 + lane_e, px = idx >> 3, sl = idx & 7;
+                    const int idx = it * 64 + lane, px = idx >> 3, sl = idx & 7;
                     const float4 v = *reinterpret_cast<const float4 *>(stg + px * 32 + ((sl ^ (px & 7)) << 2));
-                    const int q = qw + px;
-                    const size_t gidx = ((size_t)n_e * TV + q) * C + ob + 4 * sl;
-                    if (q <= qlast_e) {
-                        if constexpr (BF16OUT)
-                            *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + gidx) =
-                                make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-                        else
-                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + gidx) = v;
+                    if (full || qw + px <= g.q_last) {
+                        if constexpr (BF16OUT) {
+                            unsigned short *yb = reinterpret_cast<unsigned short *>(y) + tbase + (size_t)(it * 8) * C;
+                            *reinterpret_cast<uint2 *>(yb + lterm) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                        } else {
+                            float *yb = reinterpret_cast<float *>(y) + tbase + (size_t)(it * 8) * C;
+                            *reinterpret_cast<float4 *>(yb + lterm) = v;
+                        }
                     }
                 }
             }
         } else {
+            // element offset of (row = idx>>4, 4-pixel group c4 = 4*(idx&15)) for idx = it*64 + lane: (it*4 + lane>>4)*TV + 4*(lane&15)
+            const unsigned lterm = (unsigned)((lane >> 4) * TV + 4 * (lane & 15));
+            const int c4l = 4 * (lane & 15);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int ob = cg * 128 + m * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int cr = (r & 3) + 8 * (r >> 2) + 4 * (lane_e >> 5);
+                    const int cr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const float sh = shift[ob + cr];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) stg[cr * 64 + j * 32 + (lane_e & 31)] = fmaxf(acc[m][j][r] + sh, 0.f);
+                    for (int j = 0; j < 2; ++j) stg[cr * 64 + j * 32 + (lane & 31)] = fmaxf(acc[m][j][r] + sh, 0.f);
                 }
+                const size_t tbase = ((size_t)n * C + ob) * TV + qw;      // scalar
+                const bool al16 = ((tbase & 3) == 0) && (TV % 4 == 0);    // 16-byte (8-byte for bf16) aligned rows
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
-                    const int idx = it * 64 + lane_e, row = idx >> 4, c4 = (idx & 15) * 4;
-                    const float4 v = *reinterpret_cast<const float4 *>(stg + row * 64 + c4);
-                    const int q = qw + c4;
-                    const size_t gidx = ((size_t)n_e * C + ob + row) * TV + q;
-                    if (q + 3 <= qlast_e && (!BF16OUT || (gidx & 1) == 0)) {
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + (it * 4 + (lane >> 4)) * 64 + c4l);
+                    const size_t sbase = tbase + (size_t)(it * 4) * TV;    // scalar
+                    if (full && al16) {
                         if constexpr (BF16OUT)
-                            *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + gidx) =
+                            *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + sbase + lterm) =
                                 make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
                         else
-                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + gidx) = v;
-                    } else {                                     // ragged end of the clip
+                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + sbase + lterm) = v;
+                    } else {                                     // last tile of a clip / unaligned rows: element by element
                         const float e4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (q + e <= qlast_e) store_out<BF16OUT>(y, gidx + e, e4[e]);
+                            if (qw + c4l + e <= g.q_last) store_out<BF16OUT>(y, sbase + lterm + e, e4[e]);
                     }
                 }
             }
         }
+        V5_STAMP(t_3)
+        V5_ACC(3, t_2, t_3)
         if (next_tile < ntiles) {             // its fragments landed at the last stage barrier, its x during the stores;
             feature_phase(next_tile, xn0, xn1, xn2);   // Fs lies behind the staging area: no barrier needed in front
+            V5_STAMP(t_4)
+            V5_ACC(5, t_3, t_4)
             __syncthreads();                  // Fs complete, every wave's staging reads done (chunk 0 overwrites buf0)
         }
+        V5_STAMP(t_5)
+        V5_ACC(4, t_3, t_5)
     }
+#ifdef STGCN_ABLATION
+    if (dbg && lane == 0 && blockIdx.x < 8 && blockIdx.y == 0)
+        for (int i = 0; i < 8; ++i) dbg[(blockIdx.x * 8 + wave) * 8 + i] = tsum[i];
+#endif
 }
 
 struct V5Plan {
@@ -501,12 +548,12 @@ int launch_v5(const uint4 *pf, const float *x, int xsc, int xsp, const float *W1
         auto kern = stem_bf16_v5_kernel<PB, TERMS, true>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT5), pl.lds, st, pf, x, xsc, xsp, W12, Wp, shift, y, C, T, V, pl.rows,
-                           pl.tiles_per_clip, ntiles, opt);
+                           pl.tiles_per_clip, ntiles, opt, debug_buffer());
     } else {
         auto kern = stem_bf16_v5_kernel<PB, TERMS, false>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT5), pl.lds, st, pf, x, xsc, xsp, W12, Wp, shift, y, C, T, V, pl.rows,
-                           pl.tiles_per_clip, ntiles, opt);
+                           pl.tiles_per_clip, ntiles, opt, debug_buffer());
     }
     STGCN_LAUNCH_CHECK("stem_bf16_v5_kernel");
     return STGCN_OK;

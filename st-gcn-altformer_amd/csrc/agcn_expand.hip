@@ -94,6 +94,88 @@ __global__ __launch_bounds__(256) void agcn_expand_small_kernel(
     }
 }
 
+// The same with FOUR consecutive pixels per thread and 16-byte stores.  One dword per lane and channel (above) is bound by
+// store issue, not HBM: ~7 B/clk/CU, 3.8 TB/s measured on 256 clips; 16 B per lane doubles what a CU can issue, which
+// leaves HBM as the bound.  Needs T*V % 4 == 0 and frame chunks of a multiple of 4 pixels (16-byte aligned rows).
+template <int CIN, int S>
+__global__ __launch_bounds__(256) void agcn_expand_small4_kernel(
+    const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ Wd,
+    const float *__restrict__ bd, const float *__restrict__ Wdown, const float *__restrict__ bdown,
+    const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
+    const float *__restrict__ down_scale, const float *__restrict__ down_shift,
+    float *__restrict__ y, int Cout, int T, int V, int TF, int mode) {
+    constexpr int F = (S + 1) * CIN;
+    constexpr int FP = (F + 1 + 3) / 4 * 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * TF;
+    const int tf = min(TF, T - t0);
+    const int px = tf * V;                     // multiple of 4 (host side)
+    const int PXM = TF * V;
+    float *Ws = smem;                          // [Cout][FP]
+    float *Ps = Ws + (size_t)Cout * FP;        // [S][V][V]
+    float *Xs = Ps + S * V * V;                // [CIN][PXM]
+    for (int e = tid; e < Cout * FP; e += 256) {
+        const int o = e / FP, f = e - o * FP;
+        float val = 0.f;
+        if (f < S * CIN) {
+            const int s = f / CIN, k = f - s * CIN;
+            val = bn_scale[o] * Wd[((size_t)s * Cout + o) * CIN + k];
+        } else if (f < F) {
+            val = down_scale[o] * Wdown[o * CIN + (f - S * CIN)];
+        } else if (f == F) {
+            float b = 0.f;
+            for (int s = 0; s < S; ++s) b += bd[s * Cout + o];
+            val = fmaf(bn_scale[o], b, bn_shift[o]) + fmaf(down_scale[o], bdown[o], down_shift[o]);
+        }
+        Ws[e] = val;
+    }
+    const float *Pn = P + (size_t)n * S * V * V;
+    for (int e = tid; e < S * V * V; e += 256) Ps[e] = Pn[e];
+    const float *xn = x + (size_t)n * CIN * T * V;
+    for (int e = tid; e < CIN * px; e += 256) {
+        const int k = e / px, p = e - k * px;
+        Xs[k * PXM + p] = xn[((size_t)k * T + t0) * V + p];
+    }
+    __syncthreads();
+    for (int p4 = tid * 4; p4 < px; p4 += 1024) {
+        float feat[4][F];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p4 + q, tt = p / V, w = p - tt * V;
+#pragma unroll
+            for (int f = 0; f < S * CIN; ++f) feat[q][f] = 0.f;
+            for (int v = 0; v < V; ++v) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float pv = Ps[(s * V + v) * V + w];
+#pragma unroll
+                    for (int k = 0; k < CIN; ++k) feat[q][s * CIN + k] = fmaf(Xs[k * PXM + tt * V + v], pv, feat[q][s * CIN + k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CIN; ++k) feat[q][S * CIN + k] = Xs[k * PXM + p];
+        }
+        float *yo = y + ((size_t)n * Cout * T + t0) * V + p4;
+        const float lo = (mode & 1) ? -__builtin_huge_valf() : 0.f;   // mode bit 0: raw (pre-activation) output
+        for (int o = 0; o < Cout; ++o) {
+            const float4 *wr = reinterpret_cast<const float4 *>(Ws + o * FP);
+            const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+            const float wv[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+            float a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] = wv[F];
+#pragma unroll
+                for (int f = 0; f < F; ++f) a[q] = fmaf(wv[f], feat[q][f], a[q]);
+            }
+            *reinterpret_cast<float4 *>(yo + (size_t)o * T * V) =
+                make_float4(fmaxf(a[0], lo), fmaxf(a[1], lo), fmaxf(a[2], lo), fmaxf(a[3], lo));
+        }
+    }
+}
+
 constexpr int OB = 32;  // output channels per register block in the generic kernel
 
 __global__ __launch_bounds__(256) void agcn_expand_generic_kernel(
@@ -174,6 +256,20 @@ int launch_agcn_expand(const float *x, const float *P, const float *Wd, const fl
         int TF = 256 / V;
         if (TF < 1) TF = 1;
         if (TF > T) TF = T;
+        if ((T * V) % 4 == 0) {                // 16-byte stores: four pixels per thread, chunks of ~1024 pixels
+            const int gran = V % 4 == 0 ? 1 : (V % 2 == 0 ? 2 : 4);      // frames per chunk such that chunk*V % 4 == 0
+            int TF4 = 1024 / V / gran * gran;
+            if (TF4 < gran) TF4 = gran;
+            if (TF4 > T) TF4 = T;               // (T*V % 4 == 0: the single chunk is aligned as well)
+            const size_t lds4 = ((size_t)Cout * FP + (size_t)S * V * V + (size_t)3 * TF4 * V) * 4;
+            if (lds4 <= (size_t)kLdsBytes) {
+                STGCN_HIP_CHECK(allow_lds(agcn_expand_small4_kernel<3, 3>, lds4));
+                hipLaunchKernelGGL((agcn_expand_small4_kernel<3, 3>), dim3(ceil_div(T, TF4), N), dim3(256), lds4, st, x, P, Wd, bd,
+                                   Wdown, bdown, bn_scale, bn_shift, down_scale, down_shift, y, Cout, T, V, TF4, mode);
+                STGCN_LAUNCH_CHECK("agcn_expand_small4_kernel");
+                return STGCN_OK;
+            }
+        }
         const size_t lds = ((size_t)Cout * FP + (size_t)S * V * V + (size_t)3 * TF * V) * 4;
         if (lds <= (size_t)kLdsBytes) {
             STGCN_HIP_CHECK(allow_lds(agcn_expand_small_kernel<3, 3>, lds));

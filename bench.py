@@ -279,11 +279,10 @@ def main():
 
     def kernel_name(math):
         from stgcn_amd import _capi
-        v4 = math in ("bf16x3", "bf16") and bool(_capi.lib().stgcn_stem_features_used(3, 128, T, V, 9, 3, F._flags(
-            {"bf16x3": F.MATH_BF16X3, "bf16": F.MATH_BF16}.get(math, 0), False)))
         if args.no_fuse:
             return "tcn_bf16_v4_kernel" if math in ("bf16x3", "bf16") else "tcn_mfma_f32_kernel"
-        return "stem_mfma_f32_kernel" if math == "f32" else ("stem_bf16_v4_kernel" if v4 else "stem_mfma_bf16_kernel")
+        fl = F._flags({"f32": F.MATH_F32, "bf16x3": F.MATH_BF16X3, "bf16": F.MATH_BF16, "f32_valu": F.MATH_F32_VALU}[math], False)
+        return _capi.lib().stgcn_stem_kernel_name(3, 128, T, V, 9, 3, fl).decode() or "?"
 
     def workload_key(math):
         return f"{int(clips_per_launch)}x{T}x{V} {math} {'two-stage' if args.no_fuse else 'fused'} {args.layout}"

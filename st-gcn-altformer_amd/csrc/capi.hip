@@ -226,6 +226,17 @@ size_t stgcn_stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int subse
     return stem_ws_bytes(N, Cin, C, T, V, K, subsets, flags);
 }
 
+const char *stgcn_stem_kernel_name(int Cin, int C, int T, int V, int K, int subsets, unsigned flags) {
+    if (Cin <= 0 || C <= 0 || T <= 0 || V <= 0 || K <= 0 || subsets <= 0) return "";
+    if (!stem_fused_supported(Cin, C, T, V, K, subsets, flags)) return "";
+    if (stem_v4_supported(Cin, C, T, V, K, subsets, flags)) {
+        if (stem_v4_features_in_kernel(C, T, V, K, flags) && stem_v5_supported(C, T, V, K, flags)) return "stem_bf16_v5_kernel";
+        return "stem_bf16_v4_kernel";
+    }
+    const unsigned math = flags & STGCN_MATH_MASK;
+    return (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) ? "stem_mfma_bf16_kernel" : "stem_mfma_f32_kernel";
+}
+
 int stgcn_stem_features_used(int Cin, int C, int T, int V, int K, int subsets, unsigned flags) {
     if (Cin <= 0 || C <= 0 || T <= 0 || V <= 0 || K <= 0 || subsets <= 0) return 0;
     return stem_v4_supported(Cin, C, T, V, K, subsets, flags) ? 1 : 0;

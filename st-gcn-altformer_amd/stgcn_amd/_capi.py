@@ -47,6 +47,7 @@ PROTOTYPES = {
     "stgcn_stem_prepare": (c_int, [_P] * 11 + [c_int] * 4 + [c_uint, _P]),
     "stgcn_stem_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
     "stgcn_stem_features_used": (c_int, [c_int] * 6 + [c_uint]),
+    "stgcn_stem_kernel_name": (c_char_p, [c_int] * 6 + [c_uint]),
     "stgcn_stem_attention": (c_int, [_P] * 7 + [c_size_t] + [c_int] * 8 + [c_uint, _P]),
     "stgcn_stem_tail_prepared": (c_int, [_P] * 2 + [c_size_t] + [_P] * 3 + [c_int] * 7 + [c_uint, _P]),
     "stgcn_stem_forward_prepared": (c_int, [_P] * 9 + [c_size_t] + [_P] + [c_int] * 8 + [c_uint, _P]),

@@ -135,6 +135,13 @@ bool stem_v5_supported(int C, int T, int V, int K, unsigned flags);
 int launch_stem_v5(const float *x, bool x_ntvc, const void *pfrag, const void *prep_w12, const void *Wp, const float *shift,
                    void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st);
 
+// ... and the same on v_mfma_f32_16x16x32_bf16 (stem_bf16_v6.hip); reads the temporal weights in its own pair order,
+// which stgcn_stem_prepare appends to the prep blob behind the 32x32x16 packing
+bool stem_v6_supported(int C, int T, int V, int K, unsigned flags);
+int launch_tcn_pack_bf16_pairs(const float *W, const float *scale, void *Wq, int Cin, int Cout, hipStream_t st);
+int launch_stem_v6(const float *x, bool x_ntvc, const void *pfrag, const void *prep_w12, const void *Wq, const float *shift,
+                   void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st);
+
 // stand-alone temporal conv in the large-tile persistent form (stem_bf16_v4.hip): K = 9, stride 1, Cout % 128 == 0
 bool tcn_v4_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
 int launch_tcn_v4(const float *x, const void *Wp, const float *shift, void *y, int N, int Cin, int Cout, int T, int V, int K,

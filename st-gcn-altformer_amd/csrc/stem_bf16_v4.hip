@@ -923,6 +923,10 @@ int launch_stem_v4(const float *x, bool x_ntvc, const float *feat, const void *p
     STGCN_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
     // the 256-pixel tile runs with one wave per SIMD where that form covers the shape (diagnostic builds: mask bit 256
     // keeps the eight-wave form for A/B runs in one process)
+    // (mask bit 1024: KF5 instead of KF6)
+    if (pl.nj == 2 && stem_v6_supported(C, T, V, K, flags) && !(ablate_mask() & (256 | 1024)))
+        return launch_stem_v6(x, x_ntvc, feat, prep_w12, (const char *)Wp + tcn_packed_bytes(C, C, K, flags), shift, out, N, C, T,
+                              V, K, flags, st);
     if (pl.nj == 2 && stem_v5_supported(C, T, V, K, flags) && !(ablate_mask() & 256))
         return launch_stem_v5(x, x_ntvc, feat, prep_w12, Wp, shift, out, N, C, T, V, K, flags, st);
     const float4 *f4 = (const float4 *)feat;

@@ -34,12 +34,11 @@ typedef __attribute__((address_space(3))) void *lptr5_t;
 
 // LDS-DMA through inline asm (see stem_bf16_v4.hip: the builtin makes hipcc wait for the DMA in front of the next ds_read)
 __device__ __forceinline__ void dma16v5(const void *g, unsigned lds_addr) {
+    // M0 = LDS destination (wave-uniform).  M0 is declared clobbered instead of saved and restored around every transfer:
+    // nothing else in these kernels lives in M0, and the three extra scalar instructions per transfer are not free when a
+    // single wave owns the SIMD (they sit in the MFMA stream).
     const unsigned lds = __builtin_amdgcn_readfirstlane(lds_addr);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(g), "s"(lds)
-                 : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds) : "memory", "m0");
 }
 __device__ __forceinline__ void dma_wait5() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -264,6 +263,7 @@ __global__ __launch_bounds__(NT5) void stem_bf16_v5_kernel(
     }
 
     int gs = 0;                               // running weight-stage counter (ring slot = gs & 1)
+    int gnext = 1 % nstage;                   // index of stage gs + 1 within a tile's stages (kept without a division)
     const int h = lane >> 5;
     for (; tile < ntiles; tile += gridDim.x) {
         const int n = tile / tiles_per_clip;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(NT5) void stem_bf16_v5_kernel(
                 // stage are 20 % of a tile when no second wave on the SIMD covers them; with 512 VGPRs per wave the 24
                 // staging registers are free.
                 uint4 wr0, wr1, wr2, wr3, wr4, wr5;   // (named scalars: an array captured by the nested lambdas went to scratch)
-                const uint4 *wnext = wsrc + (size_t)(((gs + 1) % nstage) * STG5) * 128;
+                const uint4 *wnext = wsrc + (size_t)(gnext * STG5) * 128;
                 char *wdst = ring + ((gs + 1) & 1) * STAGE5 + wave * 2 * FRAG5 + lane * 16;
                 static_for5<0, STG5>([&](auto tt_c) {
                     constexpr int tt = decltype(tt_c)::value;
@@ -409,6 +409,7 @@ __global__ __launch_bounds__(NT5) void stem_bf16_v5_kernel(
                 V5_STAMP(t_s2)
                 V5_ACC(2, t_s1, t_s2)
                 ++gs;
+                gnext = gnext + 1 == nstage ? 0 : gnext + 1;
             });
         };
         for (int ch = 0; ch + 1 < nch; ++ch) chunk(std::false_type{}, ch);

@@ -560,9 +560,15 @@ bool tcn_mfma_supported(int Cin, int Cout, int T, int V, int K, int stride, unsi
 // prep blob: [ W12 : C*W12P floats, 256-B aligned ][ packed temporal weights ]
 static size_t stem_w12_bytes(int C) { return align_up((size_t)C * W12P * sizeof(float), 256); }
 
+// bf16 modes, K = 9: a second copy of the temporal weights in KF6's pair order follows the first
+static bool stem_prep_has_pairs(int C, int K, unsigned flags) {
+    const unsigned math = flags & STGCN_MATH_MASK;
+    return (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) && K == 9 && C % 128 == 0;
+}
+
 size_t stem_prep_bytes(int Cin, int C, int K, int S, unsigned flags) {
     (void)Cin; (void)S;
-    return stem_w12_bytes(C) + tcn_packed_bytes(C, C, K, flags);
+    return stem_w12_bytes(C) + tcn_packed_bytes(C, C, K, flags) * (stem_prep_has_pairs(C, K, flags) ? 2 : 1);
 }
 
 static bool stem_shape_ok(int Cin, int C, int V, int K, int S, int T) {
@@ -594,7 +600,9 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
     hipLaunchKernelGGL(stem_fold_kernel, dim3(ceil_div(C * W12P, 256)), dim3(256), 0, st, Wd, bd, Wdown, bdown,
                        bn_scale, bn_shift, down_scale, down_shift, (float *)prep, Cin, C, S);
     STGCN_LAUNCH_CHECK("stem_fold_kernel");
-    return launch_tcn_pack(Wt, t_scale, (char *)prep + stem_w12_bytes(C), C, C, K, flags, st);
+    int rc = launch_tcn_pack(Wt, t_scale, (char *)prep + stem_w12_bytes(C), C, C, K, flags, st);
+    if (rc != STGCN_OK || !stem_prep_has_pairs(C, K, flags)) return rc;
+    return launch_tcn_pack_bf16_pairs(Wt, t_scale, (char *)prep + stem_w12_bytes(C) + tcn_packed_bytes(C, C, K, flags), C, C, st);
 }
 
 // workspace of the fused stem: [ P : N*S*V*V floats, 256-B aligned ] then ONE of

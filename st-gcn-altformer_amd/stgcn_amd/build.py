@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "include"))
 LIB = os.path.join(HERE, "libstgcn_hip.so")
-SOURCES = ["capi.hip", "agcn_attention.hip", "agcn_expand.hip", "tcn_conv.hip", "tcn_bf16.hip", "stem_bf16_v4.hip", "stem_bf16_v5.hip", "train_bn.hip", "tcn_backward.hip", "agcn_backward.hip", "agcn_train.hip", "gemm_f32.hip", "agcn_backward_generic.hip"]
+SOURCES = ["capi.hip", "agcn_attention.hip", "agcn_expand.hip", "tcn_conv.hip", "tcn_bf16.hip", "stem_bf16_v4.hip", "stem_bf16_v5.hip", "stem_bf16_v6.hip", "train_bn.hip", "tcn_backward.hip", "agcn_backward.hip", "agcn_train.hip", "gemm_f32.hip", "agcn_backward_generic.hip"]
 ARCH = "gfx950"
 
 
@@ -43,7 +43,8 @@ def build(force: bool = False, verbose: bool = False, keep_temps: bool = False, 
     unless STGCN_LIB points at it).
     """
     if ablation:
-        return _build(LIB.replace(".so", "_abl.so"), "build_abl", ["-DSTGCN_ABLATION"], verbose, keep_temps)
+        extra = os.environ.get("STGCN_EXTRA_DEFS", "").split()      # e.g. -DV6_NOFILL: one-off diagnostic variants
+        return _build(LIB.replace(".so", "_abl.so"), "build_abl", ["-DSTGCN_ABLATION"] + extra, verbose, keep_temps)
     if not force and not _stale():
         return LIB
     return _build(LIB, "build", [], verbose, keep_temps)

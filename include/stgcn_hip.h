@@ -139,7 +139,7 @@ int stgcn_stem_prepare(const float *Wd, const float *bd, const float *Wdown, con
  * P (N,S,V,V) at offset 0 (valid on return) followed by per-pixel graph-conv features for the kernels
  * that consume them, or (STGCN_IN_NTVC on the other kernels) a channel-major copy of x. */
 size_t stgcn_stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int subsets, unsigned flags);
-/* Name of the kernel stgcn_stem_tail_prepared launches for the shape ("stem_bf16_v5_kernel", "stem_bf16_v4_kernel",
+/* Name of the kernel stgcn_stem_tail_prepared launches for the shape ("stem_bf16_v6_kernel", "stem_bf16_v4_kernel",
  * "stem_mfma_bf16_kernel", "stem_mfma_f32_kernel"; "" when no fused kernel covers it) — for profilers and benchmarks
  * that match kernel names in rocprofv3 output. */
 const char *stgcn_stem_kernel_name(int Cin, int C, int T, int V, int K, int subsets, unsigned flags);

@@ -231,7 +231,6 @@ const char *stgcn_stem_kernel_name(int Cin, int C, int T, int V, int K, int subs
     if (!stem_fused_supported(Cin, C, T, V, K, subsets, flags)) return "";
     if (stem_v4_supported(Cin, C, T, V, K, subsets, flags)) {
         if (stem_v4_features_in_kernel(C, T, V, K, flags) && stem_v6_supported(C, T, V, K, flags)) return "stem_bf16_v6_kernel";
-        if (stem_v4_features_in_kernel(C, T, V, K, flags) && stem_v5_supported(C, T, V, K, flags)) return "stem_bf16_v5_kernel";
         return "stem_bf16_v4_kernel";
     }
     const unsigned math = flags & STGCN_MATH_MASK;

@@ -130,13 +130,9 @@ bool stem_v4_features_in_kernel(int C, int T, int V, int K, unsigned flags);
 int launch_stem_v4(const float *x, bool x_ntvc, const float *feat, const void *prep_w12, const void *Wp, const float *shift,
                    void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st);  // honours STGCN_OUT_NTVC
 
-// the same tile with one wave per SIMD (stem_bf16_v5.hip): 256 threads, a wave owns all 128 channels of 64 pixels
-bool stem_v5_supported(int C, int T, int V, int K, unsigned flags);
-int launch_stem_v5(const float *x, bool x_ntvc, const void *pfrag, const void *prep_w12, const void *Wp, const float *shift,
-                   void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st);
-
-// ... and the same on v_mfma_f32_16x16x32_bf16 (stem_bf16_v6.hip); reads the temporal weights in its own pair order,
-// which stgcn_stem_prepare appends to the prep blob behind the 32x32x16 packing
+// the same tile with ONE WAVE PER SIMD on v_mfma_f32_16x16x32_bf16 (stem_bf16_v6.hip: 256 threads, a wave owns all 128
+// channels of 64 pixels); reads the temporal weights in its own pair order, which stgcn_stem_prepare appends to the prep
+// blob behind the 32x32x16 packing
 bool stem_v6_supported(int C, int T, int V, int K, unsigned flags);
 int launch_tcn_pack_bf16_pairs(const float *W, const float *scale, void *Wq, int Cin, int Cout, hipStream_t st);
 int launch_stem_v6(const float *x, bool x_ntvc, const void *pfrag, const void *prep_w12, const void *Wq, const float *shift,

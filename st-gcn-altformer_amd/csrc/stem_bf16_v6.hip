@@ -1,23 +1,36 @@
-// KF6 — KF5 (one wave per SIMD, stem_bf16_v5.hip) on v_mfma_f32_16x16x32_bf16.
+// KF6 — the fused stem on the bf16 matrix cores with ONE WAVE PER SIMD (256 threads, 4 waves, up to 512 registers each) on
+// v_mfma_f32_16x16x32_bf16.  Headline kernel for V <= ~25 (the 256-pixel tile); KF4 (stem_bf16_v4.hip) keeps the rest.
 //
-// Why another shape: KF5 runs at the rate the chip sustains for issued bf16 MFMA on random operands (power-limited,
-// DESIGN.md §3) — what is left is energy per FLOP, and the 16x16x32 form delivers ~1.12-1.15x the FLOP/s of 32x32x16 under
-// that limit (MI355X_MICROARCH.md "DVFS give-back" (7); this pool: 1,836 vs 1,644 TFLOP/s with KF's LDS operand traffic,
-// tools/micro/mfma_shape.hip).  Round 1's attempt on the eight-wave kernel lost to issue slots (twice the MFMA
-// instructions, two waves per SIMD); with ONE wave per SIMD a 16-cycle MFMA leaves 8 issue cycles per gap for ~1.2
-// filler instructions per gap, which is what the loop needs.
+// Same tile, LDS images, in-kernel feature computation and producer as KF4's FK form — what changes:
+//   * ownership: a wave owns ALL 128 output channels of its 64-pixel quarter (8 x 4 accumulator blocks of 16 x 16 = 128
+//     registers).  Every weight fragment is read once by each of 4 waves instead of twice by 8, an activation fragment feeds
+//     eight channel blocks: LDS read traffic per MFMA is halved; and there is no second wave on the SIMD to lose matrix-pipe
+//     arbitration to (KF4's older waves ran ahead and then waited 23 % of their time at the stage barriers).
+//   * with nothing else on the SIMD, clumps of other instructions between MFMAs are no longer hidden, so the loop is written
+//     as SLOTS: one MFMA followed by at most a couple of fillers (compile-time loop over the slots, sched_barrier(0) after
+//     each; the `filler` lambda says which filler sits in which slot), no branches, as little scalar work as possible
+//     (division-free ring counters, M0 clobbered rather than saved around an LDS-DMA).  The first version of this kernel
+//     with KF4's fenced phases was 2.7 % SLOWER than KF4 (hipcc gathers 30-40 instructions between groups of MFMAs); a
+//     uniform branch per producer piece cost 5 %.
+//   * the MFMA shape: the kernel runs at the rate the chip sustains for issued bf16 MFMA on random operands (power-limited,
+//     DESIGN.md section 3), so what is left is energy per FLOP: the 16x16x32 form delivers ~1.12-1.15x the FLOP/s of
+//     32x32x16 under that limit (MI355X_MICROARCH.md "DVFS give-back" (7); this pool: 1,836 vs 1,644 TFLOP/s with this
+//     kernel's LDS operand traffic, tools/micro/mfma_shape.hip) — measured here as an 11 % higher clock at equal wall time
+//     before the scalar work was trimmed, 2.8 % faster than the same kernel on 32x32x16 after.
 //
-// K = 32 of one MFMA = 16 channels x TWO consecutive k-steps of KF5's flat (chunk, tap) sequence.  A tile has
+// K = 32 of one MFMA = 16 channels x TWO consecutive k-steps of the flat (16-channel chunk, tap) sequence.  A tile has
 // nch * 9 steps (72: even), so steps pair up without padding; every second chunk boundary falls inside a pair
 // (tap 8 of chunk c with tap 0 of chunk c+1: the two lane halves of a B fragment then read different image buffers).
 // The loop is written per PERIOD of 9 pairs = 2 chunks (static taps, static buffers), periods in a dynamic loop:
 //   pairs 0-2 produce chunk 2p+1 into buf1, pair 4 straddles, pairs 5-7 produce chunk 2p+2 into buf0 — one pair before
 //   the chunk's first reader, so that the reader's activation fragments can be prefetched across the barrier.
 // Weights: repacked per pair ([16-channel block][pair][hi|lo][lane] x 16 B, stgcn_stem_prepare), ring of 3 pair slots
-// (16 KiB each) filled by LDS-DMA two pairs ahead, `vmcnt(4)` + barrier per pair.  A wave keeps only the current and the
-// next 16-channel block's weight fragments in registers (read one block ahead of use).
-// Accumulators: 8 x 4 blocks of 16 x 16 (128 registers, as KF5); epilogue staged 16 channels x 64 pixels at a time.
-// Everything around the channel loop (feature phase, producer, chunk-0 production) is KF5's.
+// (16 KiB each) filled by LDS-DMA two pairs ahead — issued early in a pair, waited for (vmcnt(0)) at its end, so that at a
+// pair's start BOTH the current and the next pair are resident and published: the next pair's first fragments are read
+// before the barrier, no pair opens with an exposed LDS read.  A wave keeps only the current and the next 16-channel
+// block's weight fragments in registers (read one block ahead of use).
+// Per-tile tail: epilogue staged 16 channels x 64 pixels at a time through LDS (16-byte stores, scalar base + one per-lane
+// term), next tile's x loads in flight during the stores, feature phase, chunk-0 production.
 #include <type_traits>
 
 #include "bf16_common.h"
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
 
         // ---- epilogue: each 16-channel x 64-pixel block through this wave's 4 KiB staging slice, 16 B per lane ----------
         // D[row = channel 4*(lane>>4) + r][col = pixel lane&15] per 16x16 block.  Store addresses = scalar base + one
-        // per-lane term (see stem_bf16_v5.hip); the last tile of a clip keeps per-lane bounds checks.
+        // per-lane term; the last tile of a clip keeps per-lane bounds checks.
         XRegs xn0, xn1, xn2;                  // next tile's x: in flight while this tile's results are stored
         load_x(xn0, min(next_tile, ntiles - 1), wave);
         load_x(xn1, min(next_tile, ntiles - 1), wave + 4);

@@ -29,7 +29,7 @@ with torch.no_grad():
     os.environ["STGCN_DBG_PTR"] = hex(buf.data_ptr())
     tcn(gcn(x)); torch.cuda.synchronize()
 t = buf.cpu().view(8, 8, 8).double()
-names = ["chunk0+bar", "main loop (KF5: incl. barrier waits; KF4: stage compute)", "stage barrier wait", "epilogue", "post-epilogue (features + bar)"]
+names = ["chunk0+bar", "main loop (KF6: incl. barrier waits; KF4: stage compute)", "stage barrier wait", "epilogue", "post-epilogue (features + bar)"]
 tot = t[:, :, :5].sum(-1)
 print(f"math={a.math} abl={a.abl}: per-wave total stamped cycles: mean {tot.mean():.0f}")
 for i, nm in enumerate(names):

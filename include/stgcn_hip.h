@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STGCN_ABI_VERSION 5
+#define STGCN_ABI_VERSION 6
 
 typedef enum {
     STGCN_OK = 0,
@@ -184,27 +184,32 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
                              int N, int Cin, int Cout, int T, int V, int inter_c, int subsets,
                              void *stream);
 /* save_zm / save_zd (N,Cout,T,V): the two pre-BatchNorm branches (sum_s conv_d_s(x P_s), conv_down(x)) — asking for
- * them selects the materialising path; save_stats (4*Cout): batch mean, invstd of `bn`, then of the down BatchNorm.
- * All optional (NULL).  The backward takes zm / zd or recomputes them (NULL): */
-/* recompute: bit 0 = zm / zd are not supplied (the forward ran the moments path; they are rebuilt in the workspace);
- * bit 1 = size for the generic path — needed when an input gradient is wanted (dx != NULL), with the identity
- * residual, or for a shape outside the stem class (the call below picks the path from its arguments; size for what
- * you will ask).  0 for an invalid size. */
+ * them selects the materialising path; save_stats (STGCN_AGCN_SAVE_STATS_FLOATS(Cout) floats, 8-byte aligned): batch
+ * mean, invstd of `bn`, then of the down BatchNorm (4*Cout), followed — on the moments path only — by the 63 feature
+ * moments as doubles, which the stem-class backward reads back.  All optional (NULL). */
+#define STGCN_AGCN_SAVE_STATS_FLOATS(Cout) (4 * (Cout) + 128)
+/* recompute: bit 0 = zm / zd are not supplied (the forward ran the moments path; the generic path rebuilds them in the
+ * workspace, the stem-class path never needs them); bit 1 = size for the generic path — needed when an input gradient
+ * is wanted (dx != NULL), with the identity residual, or for a shape outside the stem class (the call below picks the
+ * path from its arguments; size for what you will ask).  0 for an invalid size. */
 size_t stgcn_agcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets, int recompute);
 /* Gradients of every parameter of unit_agcn (model/unit_agcn.py:35-62) from dy (N,Cout,T,V) in training mode:
  * dWa/dWb (S,inter_c,Cin), dba/dbb (S,inter_c), dWd (S,Cout,Cin), dbd (S,Cout), dWdown (Cout,Cin), dbdown, the
  * two BatchNorms' dgamma/dbeta (main, then "dd" = down), dPA (S,V,V), and — optionally — dx (N,Cin,T,V), the gradient
  * of the input that the deeper TCN_GCN_unit layers need (model/ST_TR/ST_TR_new.py:355-372); NULL when x is data.
  * Identity residual (Cin == Cout, unit_agcn.py:57-58): pass NULL for Wdown, bdown, the down BatchNorm tensors, zd and
- * the four down-gradient outputs.  zm / zd: the branches the forward saved, or NULL to have them rebuilt here.
- * Two implementations: one fused kernel for the stem's shape class (Cin = 3, 3 subsets, Cout in {64,128,256}, down
- * branch, no dx) and a chain of strided batched fp32-MFMA GEMMs for everything else (V <= 64, inter_c <= Cout/4). */
+ * the four down-gradient outputs.  zm / zd: the branches the forward saved, or NULL.  y: the forward's output.
+ * Two implementations:
+ *   - the stem's shape class (Cin = 3, 3 subsets, Cout in {64,128,256}, down branch, no dx) with zm == zd == NULL and
+ *     y != NULL — i.e. after a moments-path forward whose save_stats carries the feature moments: ONE pass over dy / y
+ *     (fp32 MFMA), everything else from moments (csrc/agcn_backward.hip; no branch is rebuilt, no statistics pass);
+ *   - a chain of strided batched fp32-MFMA GEMMs for everything else (V <= 64, inter_c <= Cout/4); y is not read. */
 int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *Wa, const float *ba,
                               const float *Wb, const float *bb, const float *Wd, const float *bd,
                               const float *Wdown, const float *bdown, const float *P, const float *zm,
                               const float *zd, const float *bn_weight, const float *bn_bias,
                               const float *dbn_weight, const float *dbn_bias, const float *save_stats,
-                              const float *dy, float *dWa, float *dba, float *dWb, float *dbb, float *dWd,
+                              const float *y, const float *dy, float *dWa, float *dba, float *dWb, float *dbb, float *dWd,
                               float *dbd, float *dWdown, float *dbdown, float *dgamma, float *dbeta,
                               float *ddgamma, float *ddbeta, float *dPA, float *dx, void *ws, size_t ws_bytes,
                               int N, int Cin, int Cout, int T, int V, int inter_c, int subsets, void *stream);

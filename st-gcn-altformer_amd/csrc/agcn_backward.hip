@@ -1,69 +1,361 @@
-// Backward of unit_agcn (model/unit_agcn.py:73-93) in TRAINING mode for the stem's shape class (C_in <= 4 with a
-// "down" branch), i.e. what autograd derives for
+// Backward of unit_agcn (model/unit_agcn.py:73-93) in TRAINING mode for the stem's shape class (C_in = 3, 3 subsets,
+// a "down" branch), i.e. what autograd derives for
 //   P_s  = softmax_v( Gram(Wa_s x + ba_s, Wb_s x + bb_s) / (inter_c*T) ) + A_s + PA_s
 //   u_s  = x P_s ;  zm = sum_s (Wd_s u_s + bd_s) ;  zd = Wdown x + bdown ;  y = relu( BN_m(zm) + BN_d(zd) )
-// from dy.  x is data (no dx).  After the two elementwise BatchNorm statistics passes (tcn_backward.hip) ONE kernel
-// does the rest, one workgroup per clip at a time:
-//   * per frame chunk and 32-channel block it rebuilds g = dy*[y>0] and the two pre-BatchNorm gradients
-//       dzm = gm*invm*(g - mean(g) - xhat_m*mean(g*xhat_m)),  dzd likewise            (never written to HBM)
-//   * dWd_s[o,k] += dzm[o,p]*u_s[k,p],  dbd_s[o] += dzm[o,p],  dWdown[o,k] += dzd[o,p]*x[k,p],  dbdown[o] += dzd[o,p]
-//   * du_s[k,p]  = sum_o Wd_s[o,k]*dzm[o,p] ;  dP_s[v,w] += sum_{k,t} x[k,t,v]*du_s[k,t,w]
-//   * at the end of the clip: dPA += dP ;  soft-max backward  dS = Q*(dP - colsum(Q*dP))/(inter_c*T), Q = P - A_eff ;
-//     dM_s[k,l] += sum_{t,v,w} x~[k,t,v]*dS_s[v,w]*x~[l,t,w]   (x~ = [x;1]: the 4x4 bilinear form the forward folds the
-//     two embeddings into, M_s = Wa~_s^T Wb~_s)
-// and two tiny kernels sum the per-workgroup partials in a fixed order and map dM to dWa, dba, dWb, dbb.
+// from dy.  x is data (no dx).
+//
+// MOMENT FORM.  Both pre-BatchNorm branches are LINEAR in 12 per-pixel features (u: the 9 aggregated values, x: the 3
+// inputs), and a training-mode BatchNorm's input gradient is affine in (g, z):  dz = a*g + b*z + c  per channel, with
+// g = dy*[y > 0] and (a, b, c) from the batch sums of g and g*z.  Substituting z = W.feature + bias, EVERYTHING the
+// backward needs from the two full-size tensors (dy and the ReLU mask) collapses into
+//   G[o][j]   = sum_pixels g[o,p] * F_j[p]          F = (u_0..u_8, 1, x_0..x_2)          (C_out x 13 numbers)
+//   h_f[p]    = sum_o  Wd[f][o]*gamma_m[o]*invstd_m[o] * g[o,p]                            (9 values per pixel)
+// and the second moments of the features the forward already took (agcn_train.hip):
+//   sum g        = G[.,9]            sum g*zm = Wm.G[.,0:9] + bm*G[.,9]       sum g*zd = Wdown.G[.,10:13] + bdown*G[.,9]
+//   dWd[o,f]     = a_m*G[o,f] + b_m*sum(zm*u_f) + c_m*sum(u_f),   sum(zm*u_f) = n*(Wm[o].E[u u_f] + bm[o] E[u_f])   (dWdown alike)
+//   du_f[p]      = h_f[p] + sum_f' R[f][f'] u_f'[p] + r0[f],      R = Wm^T diag(b_m) Wm,  r0 = Wm^T (b_m*bm + c_m)
+// so neither branch is rebuilt, no separate statistics pass over dy runs, and the heavy kernel reads 8 bytes per output
+// element (dy, y) instead of 12 + a rebuilt 8:
+//   1. agcn_bwd_gather_kernel   one pass over dy / y: G partials per workgroup (fp32 MFMA 16x16x4 from an LDS tile) and
+//                               h (VALU, in the registers the loads land in) -> HBM (36 B per pixel)
+//   2. reduce + finalize        G summed in fp64 in a fixed order; BatchNorm coefficients, dgamma/dbeta of both
+//                               BatchNorms, dWd, dbd, dWdown, dbdown, R, r0 (all in fp64 on a handful of numbers)
+//   3. agcn_bwd_attn_kernel     per clip: du = h + R u + r0, dP_s[v,w] = sum_{k,t} x[k,t,v] du_s[k,t,w], dPA += dP,
+//                               soft-max backward  dS = Q*(dP - colsum(Q*dP))/(inter_c*T), Q = P - A_eff, and
+//                               dM_s[k,l] += sum_{t,v,w} x~[k,t,v]*dS_s[v,w]*x~[l,t,w]   (x~ = [x;1]: the 4x4 bilinear form
+//                               the forward folds the two embeddings into, M_s = Wa~_s^T Wb~_s)
+//   4. two tiny kernels sum the per-workgroup partials in a fixed order and map dM to dWa, dba, dWb, dbb.
+// Measured (256 clips, T=180, V=22): see DESIGN.md section 6.
 #include "common.h"
 
 namespace stgcn {
 
 namespace {
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
 constexpr int PXMAX = 256;   // pixels per frame chunk
-constexpr int FP = 260;      // row pitch of the x / feature / du tiles: rows 4 banks apart (a pitch of 256 floats put all
-                             // 16 feature rows of phase (b) on the same banks: 2/3 of the LDS cycles were conflicts)
-constexpr int DP = 260;      // row pitch of the dz tiles: 16-byte aligned rows, 8 consecutive rows on distinct banks
+constexpr int FP = 260;      // row pitch of the LDS tiles (floats): 16-byte aligned rows, 16 consecutive rows on distinct
+                             // banks for the 16-byte MFMA fragment reads
 constexpr int NTB = 512;     // threads per workgroup
-constexpr int NCST = 12;     // per-channel constants (10 used)
+constexpr int CIN = 3, S = 3, SC = S * CIN, C1 = CIN + 1;
+constexpr int NG = 16;       // columns of G: 0..8 g*u_f, 9 g, 10..12 g*x_k, 13..15 zero
+constexpr int NMOM = 63;     // E[u] 9, E[u u^T] 45 (upper triangle), E[x] 3, E[x x^T] 6   (agcn_train.hip)
+constexpr int NRR = SC * SC + SC;   // R (9x9) then r0 (9)
 
-struct BnRef {
-    const float *z, *scale, *shift, *mean, *invstd, *coef;   // coef: [gamma*invstd | mean(g) | mean(g*xhat)] x C
-};
-
-template <int CIN, int S, int NOB>
-__global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
-    const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ A_eff, BnRef m, BnRef d,
-    const float *__restrict__ dy, const float *__restrict__ Wd, float *__restrict__ part_w /* [grid][Cout][WCOLS] */,
-    float *__restrict__ part_pa /* [grid][S][V][V] */, float *__restrict__ part_m /* [grid][S][C1][C1] */, int N, int Cout,
-    int T, int V, int inter_c, int TF) {
-    constexpr int SC = S * CIN, C1 = CIN + 1;
-    constexpr int WCOLS = SC + 1 + CIN + 1;          // per output channel: dWd (SC), dbd, dWdown (CIN), dbdown
+// One pass over dy and y.  Workgroup = one clip at a time, frame chunks of <= 256 pixels, channel blocks of 32:
+//   wave w owns rows 4w..4w+3 of a block, lane l the pixels 4l..4l+3 of the chunk (one 16-byte load per row and tensor,
+//   issued one block ahead: 8 loads of 16 B per lane = 64 KiB per CU in flight);
+//   g -> LDS tile (double-buffered: one barrier per block) and, in the same registers, h += (Wd*gamma*invstd)[f][o] * g;
+//   then wave (half, qg) multiplies rows half*16..+15 of the tile with the 16 feature rows over its 64 pixels
+//   (v_mfma_f32_16x16x4_f32: exact fp32 products, A = g[o][p], B = F[j][p], 4 pixels per instruction).
+template <int NOB, bool VEC>
+__global__ __launch_bounds__(NTB) void agcn_bwd_gather_kernel(
+    const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ y, const float *__restrict__ dy,
+    const float *__restrict__ wda /* [Cout][12]: Wd[f][o]*gamma[o]*invstd[o] (agcn_bwd_prep_kernel) */,
+    float *__restrict__ part_g /* [grid][Cout][NG] */, float *__restrict__ hbuf /* [N][SC][T*V] */, int N, int T, int V, int TF,
+    int abl) {
+#ifdef STGCN_ABLATION   // diagnostic builds: phases can be switched off to price them (results are then wrong)
+#define GATHER_ON(bit) (!(abl & (bit)))
+#else
+#define GATHER_ON(bit) true
+#endif
+    constexpr int Cout = NOB * 32;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: row addresses stay in SGPRs (as per-lane 64-bit
+                                                                 // values hipcc hoisted all of them out of the loops and spilled)
     const int VV = V * V;
-    float *Dm = sm;                                  // [32][DP] dzm of the channel block   (16-byte aligned rows)
-    float *Dd = Dm + 32 * DP;                        // [32][DP] dzd
-    float *Xs = Dd + 32 * DP;                        // [CIN][FP]
-    float *Fs = Xs + CIN * FP;                       // [SC][FP] u_s
-    float *DUs = Fs + SC * FP;                       // [SC][FP] du_s
-    float *cst = DUs + SC * FP;                   // [Cout][NCST] per-channel constants of the two BatchNorm backward maps
-    float *red = cst + Cout * NCST;                  // [8][S*C1*C1] block reduction of dM
-    float *Ps = red + 8 * S * C1 * C1;               // [S][V][V]  P of the clip
-    float *dPs = Ps + S * VV;                        // [S][V][V]  dP, later dS
+    float *Gt = sm;                        // [2][32][FP]  g of the channel block
+    float *Fr = Gt + 2 * 32 * FP;          // [16][FP]     feature rows: u (9), ones, x (3), zeros (3)
+    float *Ps = Fr + (NG + SC) * FP;       // [S][V][V]    (the SC rows in between: with Gt and Fr, room for the 8 waves'
+                                           //              h partials at a chunk's end)
+    static_assert(8 * SC * PXMAX <= (2 * 32 + NG + SC) * FP, "h exchange must fit in front of Ps");
+    float *Xs = Fr + 10 * FP;
     const size_t plane = (size_t)T * V;
 
-    // pre = (sm*zm + tm) + (sd*zd + td) ;  dzm = am*g + bm*zm + cm ;  dzd = ad*g + bd*zd + cd     (g = dy where pre > 0)
-    for (int c = tid; c < Cout; c += NTB) {
-        float *q = cst + c * NCST;
-        const float km = m.coef[c], c1 = m.coef[Cout + c], c2m = m.coef[2 * Cout + c], im = m.invstd[c];
-        const float kd = d.coef[c], c2d = d.coef[2 * Cout + c], id = d.invstd[c];
-        q[0] = m.scale[c]; q[1] = d.scale[c]; q[2] = m.shift[c]; q[9] = d.shift[c];
-        q[3] = km; q[4] = -km * im * c2m; q[5] = km * (im * c2m * m.mean[c] - c1);
-        q[6] = kd; q[7] = -kd * id * c2d; q[8] = kd * (id * c2d * d.mean[c] - c1);
-    }
-    float accw[NOB];                                 // column (tid & 15) of channel (tid >> 4) of block ob in part_w
+    f32x4 acc[NOB];
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) accw[ob] = 0.f;
+    for (int ob = 0; ob < NOB; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int half = wave & 1, qg = wave >> 1;
+    const int nchunks = (T + TF - 1) / TF;
+    const int nsteps = nchunks * NOB;
+
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        const float *yn = y + (size_t)n * Cout * plane, *dyn = dy + (size_t)n * Cout * plane;
+        // rows wave*4 .. +3 of block (step % NOB) of chunk (step / NOB): 16 bytes per row and tensor
+        auto issue = [&](f32x4 (&ry)[4], f32x4 (&rd)[4], int step) __attribute__((always_inline)) {
+            if (step >= nsteps || !GATHER_ON(1)) return;
+            const int ch = step / NOB, ob = step - ch * NOB;
+            const int px = min(TF, T - ch * TF) * V;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const size_t g0 = (size_t)(ob * 32 + wave * 4 + rr) * plane + (size_t)ch * TF * V;
+                const float *yr = yn + g0, *dr = dyn + g0;      // wave-uniform
+                if (VEC) {
+                    const unsigned i4 = (unsigned)min(lane, px / 4 - 1) * 4u;
+                    ry[rr] = *reinterpret_cast<const f32x4 *>(yr + i4);
+                    rd[rr] = *reinterpret_cast<const f32x4 *>(dr + i4);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned p = (unsigned)min(4 * lane + j, px - 1);
+                        ry[rr][j] = yr[p];
+                        rd[rr][j] = dr[p];
+                    }
+                }
+            }
+        };
+        f32x4 ya[4], da[4], yb[4], db[4];
+        issue(ya, da, 0);
+        __syncthreads();
+        const float *Pn = P + (size_t)n * S * VV;
+        for (int e = tid; e < S * VV; e += NTB) Ps[e] = Pn[e];
+        const float *xn = x + (size_t)n * CIN * plane;
+
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int t0 = ch * TF, px = min(TF, T - t0) * V;
+            __syncthreads();                                 // previous chunk's h exchange fully consumed
+            for (int e = tid; e < CIN * PXMAX; e += NTB) {
+                const int k = e >> 8, p = e & 255;
+                Xs[k * FP + p] = p < px ? xn[(size_t)k * plane + (size_t)t0 * V + p] : 0.f;
+            }
+            for (int e = tid; e < PXMAX; e += NTB) Fr[9 * FP + e] = e < px ? 1.f : 0.f;
+            for (int e = tid; e < 3 * FP; e += NTB) Fr[13 * FP + e] = 0.f;
+            __syncthreads();
+            if (tid < PXMAX) {                               // u_s[k] of this thread's pixel (model/unit_agcn.py:87-88)
+                float u[SC];
+#pragma unroll
+                for (int f = 0; f < SC; ++f) u[f] = 0.f;
+                if (tid < px && GATHER_ON(16)) {
+                    const int tt = tid / V, w = tid - tt * V;
+                    for (int v = 0; v < V; ++v) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const float pw = Ps[(s * V + v) * V + w];
+#pragma unroll
+                            for (int k = 0; k < CIN; ++k) u[s * CIN + k] = fmaf(Xs[k * FP + tt * V + v], pw, u[s * CIN + k]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < SC; ++f) Fr[f * FP + tid] = u[f];
+            }
+            __syncthreads();
+            f32x4 bq[4];                                     // this wave's feature fragments: B[k = pixel][n = feature row]
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi)
+                bq[qi] = *reinterpret_cast<const f32x4 *>(Fr + (lane & 15) * FP + (qg * 4 + qi) * 16 + 4 * (lane >> 4));
+            float h[SC][4];
+#pragma unroll
+            for (int f = 0; f < SC; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[f][j] = 0.f;
+
+            auto consume = [&](const f32x4 (&ry)[4], const f32x4 (&rd)[4], int ob, int buf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = wave * 4 + rr;
+                    f32x4 g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = (ry[rr][j] > 0.f && 4 * lane + j < px) ? rd[rr][j] : 0.f;
+                    *reinterpret_cast<f32x4 *>(Gt + (buf * 32 + r) * FP + 4 * lane) = g;
+                    const float *wq = wda + (ob * 32 + r) * 12;      // wave-uniform: scalar loads, SGPR operands
+#pragma unroll
+                    for (int f = 0; f < (GATHER_ON(2) ? SC : 0); ++f) {
+                        const float wf = wq[f];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) h[f][j] = fmaf(wf, g[j], h[f][j]);
+                    }
+                }
+            };
+            auto gram = [&](int ob, int buf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) {
+                    const int q = qg * 4 + qi;
+                    if (q * 16 < px && GATHER_ON(4)) {
+                        const f32x4 a = *reinterpret_cast<const f32x4 *>(Gt + (buf * 32 + half * 16 + (lane & 15)) * FP + q * 16 + 4 * (lane >> 4));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bq[qi][j], acc[ob], 0, 0, 0);
+                    }
+                }
+            };
+#pragma unroll
+            for (int ob = 0; ob < NOB; ob += 2) {
+                // (the fences keep hipcc from hoisting every block's loads to the top of the unrolled loop: 285 spills)
+                issue(yb, db, ch * NOB + ob + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(ya, da, ob, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                gram(ob, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(ya, da, ch * NOB + ob + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(yb, db, ob + 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                gram(ob + 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // h of the chunk: the 8 waves' partial sums meet in LDS (the tile, feature and Hs regions are free now and
+            // contiguous: 8 x 9 x 256 floats), each (f, pixel) is summed in wave order and stored.  (LDS float atomics
+            // took 19 us per chunk here — 344 us of the kernel's 655.)
+            __syncthreads();                                 // every wave is past its last tile / fragment read
+            if (GATHER_ON(8)) {
+                float *hp = sm + (size_t)wave * SC * PXMAX;
+#pragma unroll
+                for (int f = 0; f < SC; ++f)
+                    *reinterpret_cast<f32x4 *>(hp + f * PXMAX + 4 * lane) = f32x4{h[f][0], h[f][1], h[f][2], h[f][3]};
+            }
+            __syncthreads();
+            float *hn = hbuf + (size_t)n * SC * plane + (size_t)t0 * V;
+            for (int e = tid; e < SC * PXMAX; e += NTB) {
+                const int f = e >> 8, p = e & 255;
+                float a = sm[e];
+#pragma unroll
+                for (int w8 = 1; w8 < 8; ++w8) a += sm[(size_t)w8 * SC * PXMAX + e];
+                if (p < px) hn[(size_t)f * plane + p] = a;
+            }
+        }
+    }
+
+    // ---- partials of this workgroup: the four pixel groups of a half, summed in a fixed order -------------------
+    __syncthreads();
+    float *red = Gt;                       // [4][Cout][NG]
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            red[((size_t)qg * Cout + ob * 32 + half * 16 + 4 * (lane >> 4) + i) * NG + (lane & 15)] = acc[ob][i];
+    __syncthreads();
+    float *my_g = part_g + (size_t)blockIdx.x * Cout * NG;
+    for (int e = tid; e < Cout * NG; e += NTB)
+        my_g[e] = ((red[e] + red[Cout * NG + e]) + red[2 * Cout * NG + e]) + red[3 * Cout * NG + e];
+}
+
+__global__ __launch_bounds__(256) void agcn_bwd_prep_kernel(const float *__restrict__ Wd, const float *__restrict__ bn_w,
+                                                            const float *__restrict__ inv_m, float *__restrict__ wda, int Cout) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Cout * 12) return;
+    const int o = e / 12, f = e - o * 12;
+    wda[e] = f < SC ? Wd[((size_t)(f / CIN) * Cout + o) * CIN + (f % CIN)] * bn_w[o] * inv_m[o] : 0.f;
+}
+
+// G partials -> fp64 sums, fixed order: thread (e = tid & 31, grp = tid >> 5) adds partials grp, grp+8, ...; the 8 sub-sums of
+// an element are then added in order.
+__global__ __launch_bounds__(256) void agcn_bwd_gsum_kernel(const float *__restrict__ part_g, int parts, int total,
+                                                            double *__restrict__ G) {
+    __shared__ double sub[8][32];
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    double a = 0.0;
+    if (e < total)
+        for (int p = grp; p < parts; p += 8) a += (double)part_g[(size_t)p * total + e];
+    sub[grp][el] = a;
+    __syncthreads();
+    if (grp != 0 || e >= total) return;
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += sub[g][el];
+    G[e] = s;
+}
+
+__device__ inline double muu_at(const double *muu, int i, int j) {      // upper triangle, row-major (agcn_train.hip)
+    if (i > j) { const int t = i; i = j; j = t; }
+    return muu[i * SC - i * (i - 1) / 2 + (j - i)];
+}
+__device__ inline double mxx_at(const double *mxx, int i, int j) {
+    if (i > j) { const int t = i; i = j; j = t; }
+    return mxx[i * CIN - i * (i - 1) / 2 + (j - i)];
+}
+
+// Everything that is a function of G and the feature moments (one workgroup, fp64): see the file header.
+__global__ __launch_bounds__(256) void agcn_bwd_finalize_kernel(
+    const double *__restrict__ G, const double *__restrict__ mom, double count, const float *__restrict__ Wd,
+    const float *__restrict__ bd, const float *__restrict__ Wdown, const float *__restrict__ bdown,
+    const float *__restrict__ bn_w, const float *__restrict__ dbn_w, const float *__restrict__ stats,
+    float *__restrict__ dWd, float *__restrict__ dbd, float *__restrict__ dWdown, float *__restrict__ dbdown,
+    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ ddgamma, float *__restrict__ ddbeta,
+    float *__restrict__ rr /* NRR */, int Cout) {
+    __shared__ double bS[256], cS[256];
+    const double *mu = mom, *muu = mom + SC, *mx = mom + SC + 45, *mxx = mom + SC + 45 + CIN;
+    for (int o = threadIdx.x; o < Cout; o += 256) {
+        double w[SC], bsum = 0.0, wd[CIN];
+        for (int s = 0; s < S; ++s) {
+            bsum += (double)bd[s * Cout + o];
+            for (int k = 0; k < CIN; ++k) w[s * CIN + k] = (double)Wd[((size_t)s * Cout + o) * CIN + k];
+        }
+        for (int k = 0; k < CIN; ++k) wd[k] = (double)Wdown[o * CIN + k];
+        const double bdn = (double)bdown[o];
+        const double *Gr = G + (size_t)o * NG;
+        const double Sg = Gr[9], c1 = Sg / count;
+        const double mean_m = stats[o], inv_m = stats[Cout + o], mean_d = stats[2 * Cout + o], inv_d = stats[3 * Cout + o];
+        {   // main BatchNorm and the three conv_d
+            double gz = bsum * Sg, zsum = bsum;
+            for (int f = 0; f < SC; ++f) { gz += w[f] * Gr[f]; zsum += w[f] * mu[f]; }
+            const double dg = inv_m * (gz - mean_m * Sg), c2 = dg / count, km = (double)bn_w[o] * inv_m;
+            const double am = km, bm = -km * inv_m * c2, cm = km * (inv_m * c2 * mean_m - c1);
+            for (int f = 0; f < SC; ++f) {
+                double zu = bsum * mu[f];
+                for (int f2 = 0; f2 < SC; ++f2) zu += w[f2] * muu_at(muu, f2, f);
+                dWd[((size_t)(f / CIN) * Cout + o) * CIN + (f % CIN)] = (float)(am * Gr[f] + count * (bm * zu + cm * mu[f]));
+            }
+            const float db = (float)(am * Sg + count * (bm * zsum + cm));
+            for (int s = 0; s < S; ++s) dbd[s * Cout + o] = db;          // every bd_s adds straight into zm
+            dgamma[o] = (float)dg;
+            dbeta[o] = (float)Sg;
+            bS[o] = bm;
+            cS[o] = bm * bsum + cm;
+        }
+        {   // residual BatchNorm and the down conv
+            double gz = bdn * Sg, zsum = bdn;
+            for (int k = 0; k < CIN; ++k) { gz += wd[k] * Gr[10 + k]; zsum += wd[k] * mx[k]; }
+            const double dg = inv_d * (gz - mean_d * Sg), c2 = dg / count, kd = (double)dbn_w[o] * inv_d;
+            const double ad = kd, bdd = -kd * inv_d * c2, cd = kd * (inv_d * c2 * mean_d - c1);
+            for (int k = 0; k < CIN; ++k) {
+                double zx = bdn * mx[k];
+                for (int k2 = 0; k2 < CIN; ++k2) zx += wd[k2] * mxx_at(mxx, k2, k);
+                dWdown[o * CIN + k] = (float)(ad * Gr[10 + k] + count * (bdd * zx + cd * mx[k]));
+            }
+            dbdown[o] = (float)(ad * Sg + count * (bdd * zsum + cd));
+            ddgamma[o] = (float)dg;
+            ddbeta[o] = (float)Sg;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NRR) {
+        const int t = threadIdx.x;
+        double a = 0.0;
+        if (t < SC * SC) {
+            const int f = t / SC, f2 = t - f * SC;
+            for (int o = 0; o < Cout; ++o)
+                a += (double)Wd[((size_t)(f / CIN) * Cout + o) * CIN + (f % CIN)] * bS[o] *
+                     (double)Wd[((size_t)(f2 / CIN) * Cout + o) * CIN + (f2 % CIN)];
+        } else {
+            const int f = t - SC * SC;
+            for (int o = 0; o < Cout; ++o) a += (double)Wd[((size_t)(f / CIN) * Cout + o) * CIN + (f % CIN)] * cS[o];
+        }
+        rr[t] = (float)a;
+    }
+}
+
+// Per clip: du = h + R u + r0, dP, dPA partial, soft-max backward, dM partial (see the file header).
+__global__ __launch_bounds__(NTB) void agcn_bwd_attn_kernel(
+    const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ A_eff, const float *__restrict__ hbuf,
+    const float *__restrict__ rr, float *__restrict__ part_pa /* [grid][S][V][V] */, float *__restrict__ part_m /* [grid][S][C1][C1] */,
+    int N, int T, int V, int inter_c, int TF) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int VV = V * V;
+    float *Xs = sm;                                  // [CIN][FP]
+    float *DUs = Xs + CIN * FP;                      // [SC][FP] du_s
+    float *red = DUs + SC * FP;                      // [8][S*C1*C1] block reduction of dM
+    float *Rs = red + 8 * S * C1 * C1;               // [NRR] (padded to 96)
+    float *Ps = Rs + 96;                             // [S][V][V]  P of the clip
+    float *dPs = Ps + S * VV;                        // [S][V][V]  dP, later dS
+    const size_t plane = (size_t)T * V;
+    for (int e = tid; e < NRR; e += NTB) Rs[e] = rr[e];
     float accm[S][C1][C1];
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -71,8 +363,6 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
         for (int k = 0; k < C1; ++k)
 #pragma unroll
             for (int l = 0; l < C1; ++l) accm[s][k][l] = 0.f;
-    const int ol = tid >> 4, col = tid & 15;         // phase (b): channel within the block, column of part_w
-    const int pa = tid & 255, half = tid >> 8;       // phase (a): pixel, half of the block's 32 channels
     float *my_pa = part_pa + (size_t)blockIdx.x * S * VV;
     for (int e = tid; e < S * VV; e += NTB) my_pa[e] = 0.f;
 
@@ -81,6 +371,7 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
         const float *Pn = P + (size_t)n * S * VV;
         for (int e = tid; e < S * VV; e += NTB) { Ps[e] = Pn[e]; dPs[e] = 0.f; }
         const float *xn = x + (size_t)n * CIN * plane;
+        const float *hn = hbuf + (size_t)n * SC * plane;
         for (int t0 = 0; t0 < T; t0 += TF) {
             const int px = min(TF, T - t0) * V;
             __syncthreads();
@@ -88,9 +379,8 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
                 const int k = e / px, p = e - k * px;
                 Xs[k * FP + p] = xn[(size_t)k * plane + (size_t)t0 * V + p];
             }
-            for (int e = tid; e < SC * FP; e += NTB) DUs[e] = 0.f;
             __syncthreads();
-            if (tid < px) {                          // u_s[k] of this thread's pixel (model/unit_agcn.py:87-88)
+            if (tid < px) {                          // u_s[k] of this thread's pixel, then du = h + R u + r0
                 const int tt = tid / V, w = tid - tt * V;
                 float u[SC];
 #pragma unroll
@@ -104,89 +394,12 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
                     }
                 }
 #pragma unroll
-                for (int f = 0; f < SC; ++f) Fs[f * FP + tid] = u[f];
-            }
-            float du[SC];
+                for (int f = 0; f < SC; ++f) {
+                    float d = hn[(size_t)f * plane + (size_t)t0 * V + tid] + Rs[SC * SC + f];
 #pragma unroll
-            for (int f = 0; f < SC; ++f) du[f] = 0.f;
-            // the three full-size operands of a channel block travel HBM -> registers one block ahead of their use
-            // (12 independent loads per lane in flight; fetched in place, the tile build was a chain of load round trips)
-            float rzm[4][PXMAX / 64], rzd[4][PXMAX / 64], rdy[4][PXMAX / 64];
-            auto prefetch = [&](int ob) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const size_t g0 = ((size_t)n * Cout + ob * 32 + wave * 4 + rr) * plane + (size_t)t0 * V;
-#pragma unroll
-                    for (int i = 0; i < PXMAX / 64; ++i) {
-                        const size_t g = g0 + min(lane + 64 * i, px - 1);
-                        rzm[rr][i] = m.z[g];
-                        rzd[rr][i] = d.z[g];
-                        rdy[rr][i] = dy[g];
-                    }
+                    for (int f2 = 0; f2 < SC; ++f2) d = fmaf(Rs[f * SC + f2], u[f2], d);
+                    DUs[f * FP + tid] = d;
                 }
-            };
-            prefetch(0);
-#pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) {
-                __syncthreads();                     // Fs complete / previous block consumed
-                // rebuild dzm, dzd of channels ob*32 .. +31: wave w owns rows 4w .. 4w+3, lanes stride the pixels
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int r = wave * 4 + rr, c = ob * 32 + r;
-                    const float *q = cst + c * NCST;
-                    const float s_m = q[0], s_d = q[1], t_m = q[2], t_d = q[9], am = q[3], bm = q[4], cm = q[5], ad = q[6], bd = q[7],
-                                cd = q[8];
-#pragma unroll
-                    for (int i = 0; i < PXMAX / 64; ++i) {
-                        const int p = lane + 64 * i;
-                        const float zm = rzm[rr][i], zd = rzd[rr][i];
-                        const float gg = fmaf(zm, s_m, t_m) + fmaf(zd, s_d, t_d) > 0.f ? rdy[rr][i] : 0.f;   // the forward's own expression
-                        if (p < px) {
-                            Dm[r * DP + p] = fmaf(am, gg, fmaf(bm, zm, cm));
-                            Dd[r * DP + p] = fmaf(ad, gg, fmaf(bd, zd, cd));
-                        }
-                    }
-                }
-                if (ob + 1 < NOB) prefetch(ob + 1);
-                __syncthreads();
-                if (pa < px) {                       // (a) du_s[k] += Wd_s[o][k] * dzm[o], this half's 16 channels
-                    for (int r = half * 16; r < half * 16 + 16; ++r) {
-                        const float dv = Dm[r * DP + pa];
-                        const int o = ob * 32 + r;   // (wave-uniform: the weights come through scalar loads)
-#pragma unroll
-                        for (int s = 0; s < S; ++s)
-#pragma unroll
-                            for (int k = 0; k < CIN; ++k)
-                                du[s * CIN + k] = fmaf(Wd[((size_t)s * Cout + o) * CIN + k], dv, du[s * CIN + k]);
-                    }
-                }
-                if (col < WCOLS) {                   // (b) column `col` of channel ob*32 + ol
-                    const bool main_side = col <= SC;
-                    const float *dr = (main_side ? Dm : Dd) + ol * DP;
-                    const bool is_bias = col == SC || col == WCOLS - 1;
-                    const float *fr = col < SC ? Fs + col * FP : Xs + (is_bias ? 0 : col - SC - 1) * FP;
-                    float a = 0.f;
-                    const int px4 = px & ~3;
-                    if (is_bias) {
-                        for (int p = 0; p < px4; p += 4) {
-                            const float4 dq = *reinterpret_cast<const float4 *>(dr + p);
-                            a += (dq.x + dq.y) + (dq.z + dq.w);
-                        }
-                        for (int p = px4; p < px; ++p) a += dr[p];
-                    } else {
-                        for (int p = 0; p < px4; p += 4) {
-                            const float4 dq = *reinterpret_cast<const float4 *>(dr + p);
-                            const float4 fq = *reinterpret_cast<const float4 *>(fr + p);
-                            a = fmaf(dq.x, fq.x, fmaf(dq.y, fq.y, fmaf(dq.z, fq.z, fmaf(dq.w, fq.w, a))));
-                        }
-                        for (int p = px4; p < px; ++p) a = fmaf(dr[p], fr[p], a);
-                    }
-                    accw[ob] += a;
-                }
-            }
-            if (pa < px) {                           // the two halves' du (a + b: order-independent)
-#pragma unroll
-                for (int f = 0; f < SC; ++f) atomicAdd(&DUs[f * FP + pa], du[f]);
             }
             __syncthreads();
             const int tf = px / V;
@@ -253,13 +466,6 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
             }
         }
     }
-
-    // ---- partials of this workgroup ------------------------------------------------------------
-    float *my_w = part_w + (size_t)blockIdx.x * Cout * WCOLS;
-    if (col < WCOLS) {
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) my_w[(size_t)(ob * 32 + ol) * WCOLS + col] = accw[ob];
-    }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -279,9 +485,8 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_kernel(
     }
 }
 
-// Sums the per-workgroup partials in a fixed order.  Workgroup = 32 output elements x 8 groups of partials: thread
-// (e = tid & 31, g = tid >> 5) adds partials g, g+8, ...; the 8 sub-sums of an element are then added in order g = 0..7.
-//   out_w [Cout][WCOLS] -> dWd (S,Cout,CIN), dbd (S,Cout), dWdown (Cout,CIN), dbdown (Cout);  dPA;  dM -> dm_out
+// Sums the per-workgroup partials of the attention kernel in a fixed order.  Workgroup = 32 output elements x 8 groups of
+// partials: thread (e = tid & 31, g = tid >> 5) adds partials g, g+8, ...; the 8 sub-sums are then added in order g = 0..7.
 template <int CIN, int S>
 __global__ __launch_bounds__(256) void agcn_bwd_reduce_kernel(
     const float *__restrict__ part_w, const float *__restrict__ part_pa, const float *__restrict__ part_m, int parts,
@@ -344,68 +549,113 @@ __global__ __launch_bounds__(256) void agcn_bwd_embed_kernel(
 }
 
 struct AgcnBwdPlan {
-    bool ok = false;
+    bool ok = false, vec = false;
     int TF = 0, grid = 0;
-    size_t lds = 0;
+    size_t lds_gather = 0, lds_attn = 0;
 };
 
-inline AgcnBwdPlan plan_agcn_bwd(int N, int Cin, int Cout, int T, int V, int S) {
+inline AgcnBwdPlan plan_agcn_bwd(int N, int Cin, int Cout, int T, int V, int S_) {
     AgcnBwdPlan pl;
-    if (Cin != 3 || S != 3 || (Cout != 64 && Cout != 128 && Cout != 256) || V > PXMAX) return pl;
-    const int SC = S * Cin, C1 = Cin + 1;
+    if (Cin != CIN || S_ != S || (Cout != 64 && Cout != 128 && Cout != 256) || V > 64) return pl;
+    const size_t plane = (size_t)T * V;
     int TF = PXMAX / V;
     if (TF > T) TF = T;
-    const size_t fl = (size_t)2 * 32 * DP + (size_t)(Cin + 2 * SC) * FP + (size_t)Cout * NCST + (size_t)8 * S * C1 * C1 +
-                      (size_t)2 * S * V * V;
-    pl.lds = fl * 4;
-    if (pl.lds > (size_t)kLdsBytes) return pl;
+    pl.vec = plane % 4 == 0;
+    if (pl.vec)                                          // 16-byte loads: every chunk starts on a multiple of 4 pixels
+        while (TF > 1 && (TF * V) % 4 != 0) --TF;
+    if (pl.vec && (TF * V) % 4 != 0) pl.vec = false;
+    pl.lds_gather = ((size_t)2 * 32 * FP + (size_t)NG * FP + (size_t)SC * FP + (size_t)S * V * V) * 4;
+    pl.lds_attn = ((size_t)(CIN + SC) * FP + (size_t)8 * S * C1 * C1 + 96 + (size_t)2 * S * V * V) * 4;
+    if (pl.lds_gather > (size_t)kLdsBytes || pl.lds_attn > (size_t)kLdsBytes) return pl;
+    if ((size_t)4 * Cout * NG > (size_t)2 * 32 * FP) return pl;   // the final reduction reuses the g tile
     pl.TF = TF;
     pl.grid = N < 256 ? N : 256;
     pl.ok = true;
     return pl;
 }
 
-}  // namespace
-
-bool agcn_bwd_supported(int N, int Cin, int Cout, int T, int V, int S) { return plan_agcn_bwd(N, Cin, Cout, T, V, S).ok; }
-
-// partials: [grid][Cout][WCOLS] + [grid][S][V][V] + [grid][S][C1][C1] floats, then the summed dM (S*C1*C1)
-size_t agcn_bwd_part_bytes(int N, int Cin, int Cout, int T, int V, int S) {
-    const AgcnBwdPlan pl = plan_agcn_bwd(N, Cin, Cout, T, V, S);
-    if (!pl.ok) return 0;
-    const int C1 = Cin + 1, WCOLS = S * Cin + 1 + Cin + 1;
-    return ((size_t)pl.grid * ((size_t)Cout * WCOLS + (size_t)S * V * V + (size_t)S * C1 * C1) + (size_t)S * C1 * C1) *
-           sizeof(float);
+// workspace of the fused path (bytes, each block 256-aligned):
+//   [G: Cout*NG doubles][rr: 96 floats][dM sum: S*C1*C1 floats][wda: Cout*12 floats] | part_g [grid][Cout][NG] | hbuf [N][SC][T*V]
+//   | part_pa [grid][S][V][V] | part_m [grid][S][C1][C1]
+struct AgcnBwdWs {
+    size_t g = 0, rr = 0, dm = 0, wda = 0, part_g = 0, hbuf = 0, part_pa = 0, part_m = 0, total = 0;
+};
+inline AgcnBwdWs ws_layout(const AgcnBwdPlan &pl, int N, int Cout, int T, int V) {
+    AgcnBwdWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
+    w.g = take((size_t)Cout * NG * sizeof(double));
+    w.rr = take(96 * sizeof(float));
+    w.dm = take((size_t)S * C1 * C1 * sizeof(float));
+    w.wda = take((size_t)Cout * 12 * sizeof(float));
+    w.part_g = take((size_t)pl.grid * Cout * NG * sizeof(float));
+    w.hbuf = take((size_t)N * SC * T * V * sizeof(float));
+    w.part_pa = take((size_t)pl.grid * S * V * V * sizeof(float));
+    w.part_m = take((size_t)pl.grid * S * C1 * C1 * sizeof(float));
+    w.total = off;
+    return w;
 }
 
-// m_* / d_*: z, scale, shift, mean, invstd, coef of the main / down BatchNorm (coef from launch_bn_bwd_finalize)
-int launch_agcn_bwd(const float *x, const float *P, const float *A_eff, const float *const m_[6], const float *const d_[6],
-                    const float *dy, const float *Wa, const float *ba, const float *Wb, const float *bb, const float *Wd,
-                    float *part, float *dWa, float *dba, float *dWb, float *dbb, float *dWd, float *dbd, float *dWdown,
-                    float *dbdown, float *dPA, int N, int Cin, int Cout, int T, int V, int inter_c, int S, hipStream_t st) {
-    const AgcnBwdPlan pl = plan_agcn_bwd(N, Cin, Cout, T, V, S);
+}  // namespace
+
+bool agcn_bwd_supported(int N, int Cin, int Cout, int T, int V, int S_) { return plan_agcn_bwd(N, Cin, Cout, T, V, S_).ok; }
+
+size_t agcn_bwd_ws_bytes(int N, int Cin, int Cout, int T, int V, int S_) {
+    const AgcnBwdPlan pl = plan_agcn_bwd(N, Cin, Cout, T, V, S_);
+    return pl.ok ? ws_layout(pl, N, Cout, T, V).total : 0;
+}
+
+// y: the forward's output (the ReLU mask); stats: the forward's save_stats (4*Cout floats: batch mean / invstd of both
+// BatchNorms, then the 63 feature moments as doubles — agcn_train.hip)
+int launch_agcn_bwd(const float *x, const float *P, const float *A_eff, const float *y, const float *dy, const float *Wa,
+                    const float *ba, const float *Wb, const float *bb, const float *Wd, const float *bd, const float *Wdown,
+                    const float *bdown, const float *bn_w, const float *dbn_w, const float *stats, void *ws, float *dWa,
+                    float *dba, float *dWb, float *dbb, float *dWd, float *dbd, float *dWdown, float *dbdown, float *dgamma,
+                    float *dbeta, float *ddgamma, float *ddbeta, float *dPA, int N, int Cin, int Cout, int T, int V, int inter_c,
+                    int S_, hipStream_t st) {
+    const AgcnBwdPlan pl = plan_agcn_bwd(N, Cin, Cout, T, V, S_);
     if (!pl.ok)
         return fail(STGCN_ERR_UNSUPPORTED,
-                    "agcn backward covers Cin=3, 3 subsets, Cout in {64,128,256} with a down branch (got Cin=%d S=%d Cout=%d V=%d)",
-                    Cin, S, Cout, V);
-    const int C1 = Cin + 1, WCOLS = S * Cin + 1 + Cin + 1;
-    float *part_w = part, *part_pa = part_w + (size_t)pl.grid * Cout * WCOLS, *part_m = part_pa + (size_t)pl.grid * S * V * V;
-    float *dm_sum = part_m + (size_t)pl.grid * S * C1 * C1;
-    const BnRef m{m_[0], m_[1], m_[2], m_[3], m_[4], m_[5]}, d{d_[0], d_[1], d_[2], d_[3], d_[4], d_[5]};
-#define LAUNCH_BWD(NOB)                                                                                          \
-    do {                                                                                                         \
-        STGCN_HIP_CHECK(allow_lds((agcn_bwd_kernel<3, 3, NOB>), pl.lds));                                        \
-        hipLaunchKernelGGL((agcn_bwd_kernel<3, 3, NOB>), dim3(pl.grid), dim3(NTB), pl.lds, st, x, P, A_eff, m, d, dy, \
-                           Wd, part_w, part_pa, part_m, N, Cout, T, V, inter_c, pl.TF);                          \
+                    "agcn backward (moment form) covers Cin=3, 3 subsets, Cout in {64,128,256} with a down branch (got Cin=%d S=%d Cout=%d V=%d)",
+                    Cin, S_, Cout, V);
+    const AgcnBwdWs w = ws_layout(pl, N, Cout, T, V);
+    char *base = (char *)ws;
+    double *G = (double *)(base + w.g);
+    float *rr = (float *)(base + w.rr), *dm_sum = (float *)(base + w.dm), *part_g = (float *)(base + w.part_g);
+    float *wda = (float *)(base + w.wda);
+    float *hbuf = (float *)(base + w.hbuf), *part_pa = (float *)(base + w.part_pa), *part_m = (float *)(base + w.part_m);
+    const double *mom = (const double *)(stats + 4 * Cout);
+    hipLaunchKernelGGL(agcn_bwd_prep_kernel, dim3(ceil_div(Cout * 12, 256)), dim3(256), 0, st, Wd, bn_w, stats + Cout, wda, Cout);
+    STGCN_LAUNCH_CHECK("agcn_bwd_prep_kernel");
+#define LAUNCH_GATHER(NOB, VEC)                                                                                        \
+    do {                                                                                                               \
+        STGCN_HIP_CHECK(allow_lds((agcn_bwd_gather_kernel<NOB, VEC>), pl.lds_gather));                                 \
+        hipLaunchKernelGGL((agcn_bwd_gather_kernel<NOB, VEC>), dim3(pl.grid), dim3(NTB), pl.lds_gather, st, x, P, y, dy, wda, \
+                           part_g, hbuf, N, T, V, pl.TF, ablate_mask());                                         \
     } while (0)
-    if (Cout == 64) LAUNCH_BWD(2);
-    else if (Cout == 128) LAUNCH_BWD(4);
-    else LAUNCH_BWD(8);
-#undef LAUNCH_BWD
-    STGCN_LAUNCH_CHECK("agcn_bwd_kernel");
-    const int total = Cout * WCOLS + S * V * V + S * C1 * C1;
-    hipLaunchKernelGGL((agcn_bwd_reduce_kernel<3, 3>), dim3(ceil_div(total, 32)), dim3(256), 0, st, part_w, part_pa, part_m,
-                       pl.grid, dWd, dbd, dWdown, dbdown, dPA, dm_sum, Cout, V);
+    if (pl.vec) {
+        if (Cout == 64) LAUNCH_GATHER(2, true);
+        else if (Cout == 128) LAUNCH_GATHER(4, true);
+        else LAUNCH_GATHER(8, true);
+    } else {
+        if (Cout == 64) LAUNCH_GATHER(2, false);
+        else if (Cout == 128) LAUNCH_GATHER(4, false);
+        else LAUNCH_GATHER(8, false);
+    }
+#undef LAUNCH_GATHER
+    STGCN_LAUNCH_CHECK("agcn_bwd_gather_kernel");
+    hipLaunchKernelGGL(agcn_bwd_gsum_kernel, dim3(ceil_div(Cout * NG, 32)), dim3(256), 0, st, part_g, pl.grid, Cout * NG, G);
+    STGCN_LAUNCH_CHECK("agcn_bwd_gsum_kernel");
+    hipLaunchKernelGGL(agcn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, G, mom, (double)N * T * V, Wd, bd, Wdown, bdown, bn_w,
+                       dbn_w, stats, dWd, dbd, dWdown, dbdown, dgamma, dbeta, ddgamma, ddbeta, rr, Cout);
+    STGCN_LAUNCH_CHECK("agcn_bwd_finalize_kernel");
+    STGCN_HIP_CHECK(allow_lds(agcn_bwd_attn_kernel, pl.lds_attn));
+    hipLaunchKernelGGL(agcn_bwd_attn_kernel, dim3(pl.grid), dim3(NTB), pl.lds_attn, st, x, P, A_eff, hbuf, rr, part_pa, part_m, N,
+                       T, V, inter_c, pl.TF);
+    STGCN_LAUNCH_CHECK("agcn_bwd_attn_kernel");
+    const int total = S * V * V + S * C1 * C1;
+    hipLaunchKernelGGL((agcn_bwd_reduce_kernel<3, 3>), dim3(ceil_div(total, 32)), dim3(256), 0, st, (const float *)nullptr, part_pa,
+                       part_m, pl.grid, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, dPA, dm_sum, 0, V);
     STGCN_LAUNCH_CHECK("agcn_bwd_reduce_kernel");
     hipLaunchKernelGGL((agcn_bwd_embed_kernel<3, 3>), dim3(1), dim3(256), 0, st, dm_sum, Wa, ba, Wb, bb, dWa, dba, dWb, dbb,
                        inter_c);

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void agcn_moments_finalize_kernel(
     const float *__restrict__ bn_b, float *__restrict__ bn_rm, float *__restrict__ bn_rv, const float *__restrict__ dbn_w,
     const float *__restrict__ dbn_b, float *__restrict__ dbn_rm, float *__restrict__ dbn_rv, float momentum, float eps,
     float *__restrict__ s_m, float *__restrict__ t_m, float *__restrict__ s_d, float *__restrict__ t_d,
-    float *__restrict__ save_stats /* 4*Cout or NULL */, int Cout) {
+    float *__restrict__ save_stats /* 4*Cout + 128 floats, or NULL */, int Cout) {
     constexpr int SC = S * CIN;
     __shared__ double mom[NMOM];
     __shared__ double sub[4][64];
@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256) void agcn_moments_finalize_kernel(
         sub[grp][i] = s;
     }
     __syncthreads();
-    if (tid < NMOM) mom[tid] = (((sub[0][tid] + sub[1][tid]) + sub[2][tid]) + sub[3][tid]) / count;
+    if (tid < NMOM) {
+        mom[tid] = (((sub[0][tid] + sub[1][tid]) + sub[2][tid]) + sub[3][tid]) / count;
+        // the backward's moment form (agcn_backward.hip) reads the feature moments back: 63 doubles behind the 4*Cout floats
+        if (save_stats) reinterpret_cast<double *>(save_stats + 4 * Cout)[tid] = mom[tid];
+    }
     __syncthreads();
     const double *mu = mom, *muu = mom + SC, *mx = mom + SC + 45, *mxx = mom + SC + 45 + CIN;
     for (int o = tid; o < Cout; o += 256) {

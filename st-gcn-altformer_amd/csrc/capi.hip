@@ -378,10 +378,11 @@ __global__ static void identity_residual_grad_kernel(const float *__restrict__ z
     dx[e] = (fmaf(zm[e], sm[c], tm[c]) + x[e] > 0.f) ? dy[e] : 0.f;
 }
 
-// The fused single-kernel backward serves the stem's shape class when no input gradient is wanted; everything else
-// (any Cin / Cout / subsets, identity residual, dx) takes the generic GEMM chain.
-static bool agcn_bwd_use_fused(int N, int Cin, int Cout, int T, int V, int S, bool has_down, bool want_dx) {
-    return has_down && !want_dx && agcn_bwd_supported(N, Cin, Cout, T, V, S);
+// The moment-form backward (agcn_backward.hip) serves the stem's shape class after a moments-path forward when no input
+// gradient is wanted; everything else (any Cin / Cout / subsets, identity residual, dx, saved branches) takes the generic
+// GEMM chain.
+static bool agcn_bwd_use_fused(int N, int Cin, int Cout, int T, int V, int S, bool has_down, bool want_dx, bool moments) {
+    return has_down && !want_dx && moments && agcn_bwd_supported(N, Cin, Cout, T, V, S);
 }
 static size_t agcn_bwd_generic_bytes(int N, int Cin, int Cout, int T, int V, int S) {
     const int inter_c = Cout / 4 > 0 ? Cout / 4 : 1;   // upper bound used for sizing: unit_agcn's coff_embedding = 4
@@ -393,16 +394,18 @@ static size_t agcn_bwd_generic_bytes(int N, int Cin, int Cout, int T, int V, int
 size_t stgcn_agcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int subsets, int recompute) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || subsets <= 0 || V > 64) return 0;
     const size_t branches = (recompute & 1) ? (size_t)2 * N * Cout * T * V * sizeof(float) : 0;
-    const size_t part = agcn_bwd_part_bytes(N, Cin, Cout, T, V, subsets);
-    if (part && !(recompute & 2)) return agcn_bwd_small_bytes(Cout) + align_up(part, 256) + branches;
-    return agcn_bwd_small_bytes(Cout) + agcn_bwd_generic_bytes(N, Cin, Cout, T, V, subsets) + branches;
+    const size_t fused = agcn_bwd_ws_bytes(N, Cin, Cout, T, V, subsets);
+    if (fused && !(recompute & 2)) return fused;                      // the moment form: needs neither branch
+    const size_t generic = agcn_bwd_small_bytes(Cout) + agcn_bwd_generic_bytes(N, Cin, Cout, T, V, subsets) + branches;
+    return generic > fused ? generic : fused;
 }
 
 int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *Wa, const float *ba, const float *Wb,
                               const float *bb, const float *Wd, const float *bd, const float *Wdown, const float *bdown,
                               const float *P, const float *zm, const float *zd, const float *bn_weight,
                               const float *bn_bias, const float *dbn_weight, const float *dbn_bias,
-                              const float *save_stats, const float *dy, float *dWa, float *dba, float *dWb, float *dbb,
+                              const float *save_stats, const float *y, const float *dy, float *dWa, float *dba, float *dWb,
+                              float *dbb,
                               float *dWd, float *dbd, float *dWdown, float *dbdown, float *dgamma, float *dbeta,
                               float *ddgamma, float *ddbeta, float *dPA, float *dx, void *ws, size_t ws_bytes, int N, int Cin,
                               int Cout, int T, int V, int inter_c, int subsets, void *stream) {
@@ -421,22 +424,26 @@ int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *W
     }
     if (V > 64) return fail(STGCN_ERR_UNSUPPORTED, "agcn_backward: V=%d > 64", V);
     if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "agcn_backward: N=%d > 65535 clips per call", N);
-    if (inter_c > (Cout / 4 > 0 ? Cout / 4 : 1) && !agcn_bwd_use_fused(N, Cin, Cout, T, V, subsets, has_down, dx != nullptr))
+    // the stem-class moment form wants what a moments-path forward leaves: no saved branches, the output y, the moments
+    const bool fused = agcn_bwd_use_fused(N, Cin, Cout, T, V, subsets, has_down, dx != nullptr, zm == nullptr && y != nullptr);
+    if (inter_c > (Cout / 4 > 0 ? Cout / 4 : 1) && !fused)
         return fail(STGCN_ERR_UNSUPPORTED, "agcn_backward: inter_c=%d > Cout/4 (workspace is sized for coff_embedding >= 4)", inter_c);
     if (has_down ? ((zm == nullptr) != (zd == nullptr)) : (zd != nullptr))
         return fail(STGCN_ERR_ARG, "agcn_backward: give both saved branches or neither (zd only with a down branch)");
-    const bool fused = agcn_bwd_use_fused(N, Cin, Cout, T, V, subsets, has_down, dx != nullptr);
     const bool recompute = zm == nullptr;
     const size_t need = stgcn_agcn_backward_ws_bytes(N, Cin, Cout, T, V, subsets, (recompute ? 1 : 0) | (fused ? 0 : 2));
     if (ws_bytes < need) return fail(STGCN_ERR_WORKSPACE, "agcn_backward: workspace %zu B < %zu B", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
+    if (fused)
+        return launch_agcn_bwd(x, P, A_eff, y, dy, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn_weight, dbn_weight, save_stats, ws,
+                               dWa, dba, dWb, dbb, dWd, dbd, dWdown, dbdown, dgamma, dbeta, ddgamma, ddbeta, dPA, N, Cin, Cout,
+                               T, V, inter_c, subsets, st);
     const size_t plane = (size_t)T * V, total = (size_t)N * Cout * plane;
     double *sums = (double *)ws;
     float *coefm = (float *)(sums + 3 * Cout), *coefd = coefm + 3 * Cout, *sm_ = coefd + 3 * Cout, *tm_ = sm_ + Cout,
           *sd_ = tm_ + Cout, *td_ = sd_ + Cout, *ones = td_ + Cout, *zeros = ones + Cout;
     char *body = (char *)ws + agcn_bwd_small_bytes(Cout);
-    const size_t body_bytes = fused ? align_up(agcn_bwd_part_bytes(N, Cin, Cout, T, V, subsets), 256)
-                                    : agcn_bwd_generic_bytes(N, Cin, Cout, T, V, subsets);
+    const size_t body_bytes = agcn_bwd_generic_bytes(N, Cin, Cout, T, V, subsets);
     int rc;
     if (recompute) {   // the forward kept no branches (moments path): rebuild them with the raw-mode expansion kernel
         float *zmw = (float *)(body + body_bytes);
@@ -470,12 +477,6 @@ int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *W
     if (has_down) {
         rc = launch_bn_bwd_finalize(sums, 2, (double)N * plane, dbn_weight, inv_d, ddgamma, ddbeta, coefd, Cout, st);
         if (rc != STGCN_OK) return rc;
-    }
-    if (fused) {
-        const float *const m_[6] = {zm, sm_, tm_, mean_m, inv_m, coefm};
-        const float *const d_[6] = {zd, sd_, td_, mean_d, inv_d, coefd};
-        return launch_agcn_bwd(x, P, A_eff, m_, d_, dy, Wa, ba, Wb, bb, Wd, (float *)body, dWa, dba, dWb, dbb, dWd, dbd, dWdown,
-                               dbdown, dPA, N, Cin, Cout, T, V, inter_c, subsets, st);
     }
     // generic path: materialise both pre-BatchNorm gradients, then the GEMM chain
     float *dzm = (float *)body, *dzd = dzm + total, *gws = dzd + total;

@@ -184,11 +184,13 @@ int launch_agcn_moments(const float *x, const float *P, double *part, const floa
 
 // backward of the training-mode graph conv (agcn_backward.hip)
 bool agcn_bwd_supported(int N, int Cin, int Cout, int T, int V, int S);
-size_t agcn_bwd_part_bytes(int N, int Cin, int Cout, int T, int V, int S);
-int launch_agcn_bwd(const float *x, const float *P, const float *A_eff, const float *const m_[6], const float *const d_[6],
-                    const float *dy, const float *Wa, const float *ba, const float *Wb, const float *bb, const float *Wd,
-                    float *part, float *dWa, float *dba, float *dWb, float *dbb, float *dWd, float *dbd, float *dWdown,
-                    float *dbdown, float *dPA, int N, int Cin, int Cout, int T, int V, int inter_c, int S, hipStream_t st);
+size_t agcn_bwd_ws_bytes(int N, int Cin, int Cout, int T, int V, int S);
+int launch_agcn_bwd(const float *x, const float *P, const float *A_eff, const float *y, const float *dy, const float *Wa,
+                    const float *ba, const float *Wb, const float *bb, const float *Wd, const float *bd, const float *Wdown,
+                    const float *bdown, const float *bn_w, const float *dbn_w, const float *stats, void *ws, float *dWa,
+                    float *dba, float *dWb, float *dbb, float *dWd, float *dbd, float *dWdown, float *dbdown, float *dgamma,
+                    float *dbeta, float *ddgamma, float *ddbeta, float *dPA, int N, int Cin, int Cout, int T, int V, int inter_c,
+                    int S, hipStream_t st);
 
 // strided batched fp32 GEMM + small helpers (gemm_f32.hip): C[b][m][n] (+)= alpha * sum_k A[b][m][k] B[b][k][n] (+ bias[m])
 struct GemmArgs {

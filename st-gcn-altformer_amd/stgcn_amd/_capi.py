@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STGCN_LIB") or os.path.join(_HERE, "libstgcn_hip.so")   # STGCN_LIB: diagnostic builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # stgcn_math / flags (include/stgcn_hip.h)
 MATH_F32 = 0
@@ -56,7 +56,7 @@ PROTOTYPES = {
     "stgcn_agcn_train_ws_bytes": (c_size_t, [c_int] * 7),
     "stgcn_agcn_forward_train": (c_int, [_P] * 18 + [c_float, c_float, _P, _P, c_size_t] + [_P] * 4 + [c_int] * 7 + [_P]),
     "stgcn_agcn_backward_ws_bytes": (c_size_t, [c_int] * 7),
-    "stgcn_agcn_backward_train": (c_int, [_P] * 33 + [_P, c_size_t] + [c_int] * 7 + [_P]),
+    "stgcn_agcn_backward_train": (c_int, [_P] * 34 + [_P, c_size_t] + [c_int] * 7 + [_P]),
     "stgcn_tcn_train_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
     "stgcn_tcn_forward_train": (c_int, [_P] * 7 + [c_float, c_float, _P, c_size_t] + [_P] * 4 + [c_int] * 7 + [c_uint, _P]),
     "stgcn_tcn_backward_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),

@@ -227,9 +227,10 @@ def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_
                        save=False):
     """Training-mode forward of unit_agcn (batch-statistics BatchNorm; running buffers of `bn` / `down_bn` are
     updated in place like torch does).  bn / down_bn: (weight, bias, running_mean, running_var) tensors.
-    Returns (y, P); with ``save`` (y, P, zm, zd, stats): stats = batch mean / invstd of both BatchNorms (4*Cout);
+    Returns (y, P); with ``save`` (y, P, zm, zd, stats): stats = batch mean / invstd of both BatchNorms (4*Cout) and, on
+    the stem class's moments path, the 63 feature moments behind them (STGCN_AGCN_SAVE_STATS_FLOATS);
     zm, zd = the pre-BatchNorm branches, kept only with ``save="branches"`` (else None: the stem shape class then runs
-    the moments path, which never writes them, and the backward recomputes what it needs)."""
+    the moments path, which never writes them, and its backward works from y, dy and the moments)."""
     dev = x.device
     N, Cin, T, V = x.shape
     S, inter_c, _ = Wa.shape
@@ -242,7 +243,7 @@ def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_
     d = down_bn if down_bn is not None else (None, None, None, None)
     zm = torch.empty_like(y) if branches else None
     zd = torch.empty_like(y) if branches else None
-    stats = torch.empty(4 * Cout, device=dev, dtype=torch.float32) if save else None
+    stats = torch.empty(4 * Cout + 128, device=dev, dtype=torch.float32) if save else None
     with torch.cuda.device(dev):
         _capi.call("stgcn_agcn_forward_train", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev),
                    _dev_ptr(Wa, "Wa", dev), _dev_ptr(ba, "ba", dev), _dev_ptr(Wb, "Wb", dev), _dev_ptr(bb, "bb", dev),
@@ -262,9 +263,11 @@ def agcn_backward_supported(N, Cin, Cout, T, V, S) -> bool:
 
 
 def agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, zm, zd, bn_weight, bn_bias, dbn_weight,
-                        dbn_bias, stats, dy, need_dx=False):
-    """Gradients of the training-mode unit_agcn forward.  zm / zd: the saved pre-BatchNorm branches, or None to have
-    them rebuilt in the call's workspace.  Wdown / bdown / dbn_* None = identity residual (Cin == Cout).
+                        dbn_bias, stats, dy, need_dx=False, y=None):
+    """Gradients of the training-mode unit_agcn forward.  zm / zd: the saved pre-BatchNorm branches, or None.  y: the
+    forward's output — with it (and zm = zd = None, stats from a moments-path forward) the stem class runs its
+    one-pass moment form; otherwise the GEMM chain, which rebuilds missing branches in the call's workspace.
+    Wdown / bdown / dbn_* None = identity residual (Cin == Cout).
     Returns a dict keyed dWa, dba, dWb, dbb, dWd, dbd, dgamma, dbeta, dPA, plus dWdown, dbdown, ddgamma, ddbeta with a
     down branch and dx with ``need_dx`` (the input gradient, model/ST_TR/ST_TR_new.py:355-372)."""
     dev = x.device
@@ -292,7 +295,7 @@ def agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, zm, z
                    _dev_ptr(P, "P", dev), _dev_ptr(zm, "zm", dev), _dev_ptr(zd, "zd", dev),
                    _dev_ptr(bn_weight, "bn_weight", dev), _dev_ptr(bn_bias, "bn_bias", dev),
                    _dev_ptr(dbn_weight, "dbn_weight", dev), _dev_ptr(dbn_bias, "dbn_bias", dev),
-                   _dev_ptr(stats, "stats", dev), _dev_ptr(dy, "dy", dev),
+                   _dev_ptr(stats, "stats", dev), _dev_ptr(y, "y", dev), _dev_ptr(dy, "dy", dev),
                    *[o(k) for k in ("dWa", "dba", "dWb", "dbb", "dWd", "dbd", "dWdown", "dbdown", "dgamma",
                                     "dbeta", "ddgamma", "ddbeta", "dPA", "dx")],
                    c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), c_int(N), c_int(Cin), c_int(Cout), c_int(T),

@@ -170,9 +170,9 @@ class _AgcnTrainFn(torch.autograd.Function):
             (d.weight.detach(), d.bias.detach(), d.running_mean, d.running_var) if has_down else None,
             bn.momentum, bn.eps, save=True)
         # (zm, zd are None: the stem shape class derives its BatchNorm statistics from feature moments and writes
-        #  neither branch; the backward rebuilds what it needs in its own workspace — nothing full-size is kept in between)
+        #  neither branch; its backward works from y — which the consumer keeps anyway — dy and those moments)
         saved = [xd, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], P, bn.weight.detach(),
-                 bn.bias.detach(), stats]
+                 bn.bias.detach(), stats, y]
         if has_down:
             saved += [st["Wdown"], st["bdown"], d.weight.detach(), d.bias.detach()]
         ctx.save_for_backward(*saved)
@@ -184,11 +184,11 @@ class _AgcnTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         t = ctx.saved_tensors
-        x, A_eff, Wa, ba, Wb, bb, Wd, bd, P, bnw, bnb, stats = t[:12]
-        Wdown, bdown, dbnw, dbnb = t[12:16] if ctx.has_down else (None, None, None, None)
+        x, A_eff, Wa, ba, Wb, bb, Wd, bd, P, bnw, bnb, stats, y = t[:13]
+        Wdown, bdown, dbnw, dbnb = t[13:17] if ctx.has_down else (None, None, None, None)
         need_dx = ctx.needs_input_grad[1]
         g = F.agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, None, None, bnw, bnb, dbnw, dbnb, stats,
-                                  dy.contiguous(), need_dx=need_dx)
+                                  dy.contiguous(), need_dx=need_dx, y=y)
         S = ctx.S
         out = [g["dPA"]]
         for w, b in (("dWa", "dba"), ("dWb", "dbb"), ("dWd", "dbd")):

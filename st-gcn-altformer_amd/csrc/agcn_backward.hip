@@ -340,77 +340,206 @@ __global__ __launch_bounds__(256) void agcn_bwd_finalize_kernel(
     }
 }
 
-// Per clip: du = h + R u + r0, dP, dPA partial, soft-max backward, dM partial (see the file header).
+// Per clip, on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), ONE pass over x in frame chunks:
+//   u_s[(k,t),w]    = sum_v x[(k,t),v] P_s[v,w]                       -> LDS            (rows (k,t), 16 x 16 blocks)
+//   du              = h + R u + r0                                     VALU, <= 45 FMAs per thread
+//   dP_s[v,w]      += sum_{(k,t)} x[(k,t),v] du_s[(k,t),w]             accumulators stay in registers across the chunks
+//   X2[(k,v),(l,w)] += sum_t x~[k,t,v] x~[l,t,w]                       x~ = [x;1]; upper-triangle blocks, registers
+// then, per clip: dPA partial, soft-max backward dS = Q*(dP - colsum(Q*dP))/(inter_c*T), Q = P - A_eff, and
+//   dM_s[k][l] = sum_{v,w} dS_s[v,w] X2[(k,v),(l,w)]                   (the 4x4 bilinear form of the two embeddings)
+// Work units are dealt round-robin to the 8 waves: u blocks (subset, row block, column block), dP blocks (subset, v block,
+// w block, K part), X2 blocks (I <= J).  MAXU / MAXG: static bounds of the latter two per wave.
+constexpr int ROWTAB = 784;   // (k,t) row -> LDS offset k*FP + t*V of the chunk, -1 = no such row
+
+template <int MAXU, int MAXG>
 __global__ __launch_bounds__(NTB) void agcn_bwd_attn_kernel(
     const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ A_eff, const float *__restrict__ hbuf,
     const float *__restrict__ rr, float *__restrict__ part_pa /* [grid][S][V][V] */, float *__restrict__ part_m /* [grid][S][C1][C1] */,
-    int N, int T, int V, int inter_c, int TF) {
+    int N, int T, int V, int inter_c, int TF, int KS) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int VV = V * V;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int VV = V * V, V3 = 3 * V;
+    const int nvb = (V + 15) / 16, NGB = (V3 + 1 + 15) / 16, XP = NGB * 16 + 4;
     float *Xs = sm;                                  // [CIN][FP]
-    float *DUs = Xs + CIN * FP;                      // [SC][FP] du_s
-    float *red = DUs + SC * FP;                      // [8][S*C1*C1] block reduction of dM
-    float *Rs = red + 8 * S * C1 * C1;               // [NRR] (padded to 96)
-    float *Ps = Rs + 96;                             // [S][V][V]  P of the clip
+    float *Us = Xs + CIN * FP;                       // [SC][FP]  u_s
+    float *DUs = Us + SC * FP;                       // [SC][FP]  du_s
+    float *Rs = DUs + SC * FP;                       // [96]      R, r0
+    float *dMs = Rs + 96;                            // [48]      dM of this workgroup's clips
+    int *rowtab = reinterpret_cast<int *>(dMs + 48); // [ROWTAB]
+    float *Ps = reinterpret_cast<float *>(rowtab + ROWTAB);   // [S][V][V]  P of the clip
     float *dPs = Ps + S * VV;                        // [S][V][V]  dP, later dS
+    float *X2s = dPs + S * VV;                       // [NGB*16][XP]
     const size_t plane = (size_t)T * V;
     for (int e = tid; e < NRR; e += NTB) Rs[e] = rr[e];
-    float accm[S][C1][C1];
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-#pragma unroll
-        for (int k = 0; k < C1; ++k)
-#pragma unroll
-            for (int l = 0; l < C1; ++l) accm[s][k][l] = 0.f;
+    if (tid < 48) dMs[tid] = 0.f;
     float *my_pa = part_pa + (size_t)blockIdx.x * S * VV;
     for (int e = tid; e < S * VV; e += NTB) my_pa[e] = 0.f;
 
+    // ---- this wave's X2 blocks (I <= J): per-lane source of the A / B value: >= 0 LDS offset k*FP + v, -1 ones row, -2 zero
+    const int nblk = NGB * (NGB + 1) / 2;
+    int gI[MAXG], gJ[MAXG], goA[MAXG], goB[MAXG];
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+        int g = wave + 8 * i, I = 0;
+        if (g < nblk) {
+            while (g >= NGB - I) { g -= NGB - I; ++I; }
+            gI[i] = I; gJ[i] = I + g;
+        } else { gI[i] = -1; gJ[i] = -1; }
+        const int ia = gI[i] * 16 + l16, ib = gJ[i] * 16 + l16;
+        goA[i] = ia < V3 ? (ia / V) * FP + (ia % V) : (ia == V3 ? -1 : -2);
+        goB[i] = ib < V3 ? (ib / V) * FP + (ib % V) : (ib == V3 ? -1 : -2);
+    }
+    // ---- this wave's dP units
+    const int ncombo = S * nvb * nvb, nunits = ncombo * KS;
+    const int ksteps_d = (3 * TF + 3) / 4, kpp = (ksteps_d + KS - 1) / KS;
+    int uS[MAXU], uV[MAXU], uW[MAXU], uK0[MAXU], uK1[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        const int unit = wave + 8 * i;
+        const int kq = unit % KS, combo = unit / KS;
+        uS[i] = unit < nunits ? combo / (nvb * nvb) : -1;
+        uV[i] = (combo / nvb) % nvb;
+        uW[i] = combo % nvb;
+        uK0[i] = kq * kpp;
+        uK1[i] = min(uK0[i] + kpp, ksteps_d);
+    }
+    const int nrb = (3 * TF + 15) / 16, n_uunits = S * nrb * nvb, ksteps_u = (V + 3) / 4;
+
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        f32x4 accP[MAXU], accG[MAXG];
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) accP[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MAXG; ++i) accG[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
         const float *Pn = P + (size_t)n * S * VV;
         for (int e = tid; e < S * VV; e += NTB) { Ps[e] = Pn[e]; dPs[e] = 0.f; }
         const float *xn = x + (size_t)n * CIN * plane;
         const float *hn = hbuf + (size_t)n * SC * plane;
-        for (int t0 = 0; t0 < T; t0 += TF) {
+        // x and h of a chunk travel HBM -> registers one chunk ahead (their latency was exposed twice per chunk)
+        float xr[2], hr[5];
+        auto fetch = [&](int t0) __attribute__((always_inline)) {
             const int px = min(TF, T - t0) * V;
-            __syncthreads();
-            for (int e = tid; e < CIN * px; e += NTB) {
-                const int k = e / px, p = e - k * px;
-                Xs[k * FP + p] = xn[(size_t)k * plane + (size_t)t0 * V + p];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + i * NTB, k = e >> 8, p = e & 255;
+                xr[i] = (k < CIN && p < px) ? xn[(size_t)k * plane + (size_t)t0 * V + p] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int e = tid + i * NTB, f = e >> 8, p = e & 255;
+                hr[i] = (f < SC && p < px) ? hn[(size_t)f * plane + (size_t)t0 * V + p] : 0.f;
+            }
+        };
+        fetch(0);
+        for (int t0 = 0; t0 < T; t0 += TF) {
+            const int tf = min(TF, T - t0), px = tf * V;
+            __syncthreads();                                 // previous chunk's tiles fully consumed
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + i * NTB, k = e >> 8, p = e & 255;
+                if (k < CIN) Xs[k * FP + p] = xr[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int e = tid + i * NTB, f = e >> 8, p = e & 255;
+                if (f < SC) DUs[f * FP + p] = hr[i];
+            }
+            if (t0 + TF < T) fetch(t0 + TF);
+            for (int r = tid; r < 4 * ksteps_d + 16 && r < ROWTAB; r += NTB) {
+                const int k = r / TF, t = r - k * TF;
+                rowtab[r] = (k < CIN && t < tf) ? k * FP + t * V : -1;
             }
             __syncthreads();
-            if (tid < px) {                          // u_s[k] of this thread's pixel, then du = h + R u + r0
-                const int tt = tid / V, w = tid - tt * V;
-                float u[SC];
+            // ---- u blocks: A = x[(k,t)][v], B = P_s[v][w]
+            for (int uu = wave; uu < n_uunits; uu += 8) {
+                const int s = uu / (nrb * nvb), rb = (uu / nvb) % nrb, wb = uu % nvb;
+                const int off = rowtab[rb * 16 + l16], w = wb * 16 + l16;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < ksteps_u; ++ks) {
+                    const int v = 4 * ks + lq;
+                    const float a = (off >= 0 && v < V) ? Xs[off + v] : 0.f;
+                    const float b = (v < V && w < V) ? Ps[(s * V + v) * V + w] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+                }
 #pragma unroll
-                for (int f = 0; f < SC; ++f) u[f] = 0.f;
-                for (int v = 0; v < V; ++v) {
+                for (int i = 0; i < 4; ++i) {
+                    const int o2 = rowtab[rb * 16 + 4 * lq + i];
+                    if (o2 >= 0 && w < V) Us[s * CIN * FP + o2 + w] = acc[i];
+                }
+            }
+            // ---- X2 blocks: A = x~[(k,v)][t], B = x~[(l,w)][t]
+            {
+                const int ksteps_g = (tf + 3) / 4;
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const float pw = Ps[(s * V + v) * V + w];
-#pragma unroll
-                        for (int k = 0; k < CIN; ++k) u[s * CIN + k] = fmaf(Xs[k * FP + tt * V + v], pw, u[s * CIN + k]);
+                for (int i = 0; i < MAXG; ++i) {
+                    if (gI[i] >= 0) {
+                        for (int ks = 0; ks < ksteps_g; ++ks) {
+                            const int t = 4 * ks + lq;
+                            const bool ok = t < tf;
+                            const float a = !ok ? 0.f : (goA[i] >= 0 ? Xs[goA[i] + t * V] : (goA[i] == -1 ? 1.f : 0.f));
+                            const float b = !ok ? 0.f : (goB[i] >= 0 ? Xs[goB[i] + t * V] : (goB[i] == -1 ? 1.f : 0.f));
+                            accG[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, accG[i], 0, 0, 0);
+                        }
                     }
                 }
+            }
+            __syncthreads();
+            // ---- du = h + R u + r0: thread = (pixel, half of the 9 rows)
+            {
+                const int p = tid & 255, f0 = (tid >> 8) ? 5 : 0, f1 = (tid >> 8) ? SC : 5;
+                if (p < px) {
+                    float u[SC];
 #pragma unroll
-                for (int f = 0; f < SC; ++f) {
-                    float d = hn[(size_t)f * plane + (size_t)t0 * V + tid] + Rs[SC * SC + f];
+                    for (int f = 0; f < SC; ++f) u[f] = Us[f * FP + p];
+                    for (int f = f0; f < f1; ++f) {
+                        float d = DUs[f * FP + p] + Rs[SC * SC + f];          // (h of this pixel, staged above)
 #pragma unroll
-                    for (int f2 = 0; f2 < SC; ++f2) d = fmaf(Rs[f * SC + f2], u[f2], d);
-                    DUs[f * FP + tid] = d;
+                        for (int f2 = 0; f2 < SC; ++f2) d = fmaf(Rs[f * SC + f2], u[f2], d);
+                        DUs[f * FP + p] = d;
+                    }
                 }
             }
             __syncthreads();
-            const int tf = px / V;
-            for (int e = tid; e < S * VV; e += NTB) {  // dP_s[v][w] += sum_{k,t} x[k,t,v] * du_s[k,t,w]
-                const int s = e / VV, vw = e - s * VV, v = vw / V, w = vw - v * V;
-                float a = 0.f;
-                for (int tt = 0; tt < tf; ++tt)
+            // ---- dP blocks: A = x[(k,t)][v] (transposed use), B = du_s[(k,t)][w]
 #pragma unroll
-                    for (int k = 0; k < CIN; ++k)
-                        a = fmaf(Xs[k * FP + tt * V + v], DUs[(s * CIN + k) * FP + tt * V + w], a);
-                dPs[e] += a;
+            for (int i = 0; i < MAXU; ++i) {
+                if (uS[i] >= 0) {
+                    const int v = uV[i] * 16 + l16, w = uW[i] * 16 + l16;
+                    const float *du = DUs + uS[i] * CIN * FP;
+                    for (int ks = uK0[i]; ks < uK1[i]; ++ks) {
+                        const int off = rowtab[4 * ks + lq];
+                        const float a = (off >= 0 && v < V) ? Xs[off + v] : 0.f;
+                        const float b = (off >= 0 && w < V) ? du[off + w] : 0.f;
+                        accP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, accP[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- the clip's dP (K parts meet in LDS) and X2
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            if (uS[i] >= 0) {
+                const int w = uW[i] * 16 + l16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int v = uV[i] * 16 + 4 * lq + j;
+                    if (v < V && w < V) atomicAdd(&dPs[(uS[i] * V + v) * V + w], accP[i][j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXG; ++i) {
+            if (gI[i] >= 0) {
+                const int b = gJ[i] * 16 + l16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int a = gI[i] * 16 + 4 * lq + j;
+                    X2s[a * XP + b] = accG[i][j];
+                    if (gI[i] != gJ[i]) X2s[b * XP + a] = accG[i][j];
+                }
             }
         }
         __syncthreads();
@@ -430,59 +559,22 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_attn_kernel(
                 dPs[i] = (Ps[i] - A_eff[i]) * (dPs[i] - dot) / denom;
             }
         }
-        // dM_s[k][l] += sum_{t,v} x~[k,t,v] * ( sum_w dS_s[v,w] * x~[l,t,w] )
-        for (int t0 = 0; t0 < T; t0 += TF) {
-            const int px = min(TF, T - t0) * V;
-            __syncthreads();
-            for (int e = tid; e < CIN * px; e += NTB) {
-                const int k = e / px, p = e - k * px;
-                Xs[k * FP + p] = xn[(size_t)k * plane + (size_t)t0 * V + p];
+        __syncthreads();
+        // dM_s[k][l] += sum_{v,w} dS_s[v,w] * X2[(k,v)][(l,w)]   ((3,.) = the ones row)
+        for (int o = wave; o < S * C1 * C1; o += 8) {
+            const int s = o / (C1 * C1), k = (o / C1) % C1, l = o % C1;
+            float a = 0.f;
+            for (int e = lane; e < VV; e += 64) {
+                const int v = e / V, w = e - v * V;
+                const int ia = k < CIN ? k * V + v : V3, ib = l < CIN ? l * V + w : V3;
+                a = fmaf(dPs[s * VV + e], X2s[ia * XP + ib], a);
             }
-            __syncthreads();
-            for (int it = tid; it < S * px; it += NTB) {
-                const int s = it / px, p = it - s * px, tt = p / V, v = p - tt * V;
-                float r[C1];
-#pragma unroll
-                for (int l = 0; l < C1; ++l) r[l] = 0.f;
-                const float *ds = dPs + (s * V + v) * V;
-                for (int w = 0; w < V; ++w) {
-                    const float dsv = ds[w];
-#pragma unroll
-                    for (int l = 0; l < CIN; ++l) r[l] = fmaf(dsv, Xs[l * FP + tt * V + w], r[l]);
-                    r[CIN] += dsv;
-                }
-                float xt[C1];
-#pragma unroll
-                for (int k = 0; k < CIN; ++k) xt[k] = Xs[k * FP + p];
-                xt[CIN] = 1.f;
-#pragma unroll
-                for (int s2 = 0; s2 < S; ++s2)
-                    if (s2 == s) {
-#pragma unroll
-                        for (int k = 0; k < C1; ++k)
-#pragma unroll
-                            for (int l = 0; l < C1; ++l) accm[s2][k][l] = fmaf(xt[k], r[l], accm[s2][k][l]);
-                    }
-            }
+            for (int sh = 32; sh > 0; sh >>= 1) a += __shfl_down(a, sh, 64);
+            if (lane == 0) dMs[o] += a;
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-#pragma unroll
-        for (int k = 0; k < C1; ++k)
-#pragma unroll
-            for (int l = 0; l < C1; ++l) {
-                float v = accm[s][k][l];
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-                if (lane == 0) red[wave * S * C1 * C1 + (s * C1 + k) * C1 + l] = v;
-            }
-    __syncthreads();
-    if (tid < S * C1 * C1) {
-        float v = 0.f;
-        for (int w8 = 0; w8 < 8; ++w8) v += red[w8 * S * C1 * C1 + tid];
-        part_m[(size_t)blockIdx.x * S * C1 * C1 + tid] = v;
-    }
+    if (tid < S * C1 * C1) part_m[(size_t)blockIdx.x * S * C1 * C1 + tid] = dMs[tid];
 }
 
 // Sums the per-workgroup partials of the attention kernel in a fixed order.  Workgroup = 32 output elements x 8 groups of
@@ -550,7 +642,7 @@ __global__ __launch_bounds__(256) void agcn_bwd_embed_kernel(
 
 struct AgcnBwdPlan {
     bool ok = false, vec = false;
-    int TF = 0, grid = 0;
+    int TF = 0, grid = 0, KS = 1, cls = 0;
     size_t lds_gather = 0, lds_attn = 0;
 };
 
@@ -565,7 +657,14 @@ inline AgcnBwdPlan plan_agcn_bwd(int N, int Cin, int Cout, int T, int V, int S_)
         while (TF > 1 && (TF * V) % 4 != 0) --TF;
     if (pl.vec && (TF * V) % 4 != 0) pl.vec = false;
     pl.lds_gather = ((size_t)2 * 32 * FP + (size_t)NG * FP + (size_t)SC * FP + (size_t)S * V * V) * 4;
-    pl.lds_attn = ((size_t)(CIN + SC) * FP + (size_t)8 * S * C1 * C1 + 96 + (size_t)2 * S * V * V) * 4;
+    {   // attention kernel: instantiation class by V, K split of its dP units, LDS
+        const int nvb = (V + 15) / 16, NGB = (3 * V + 1 + 15) / 16, XP = NGB * 16 + 4;
+        pl.KS = nvb == 1 ? 8 : (nvb == 2 ? 2 : 1);
+        const int upw = (S * nvb * nvb * pl.KS + 7) / 8, gpw = (NGB * (NGB + 1) / 2 + 7) / 8;
+        pl.cls = (upw <= 3 && gpw <= 2) ? 0 : ((upw <= 4 && gpw <= 7) ? 1 : -1);
+        if (pl.cls < 0 || 3 * TF + 19 > ROWTAB) return pl;       // wider graphs: the generic GEMM chain serves them
+        pl.lds_attn = ((size_t)(CIN + 2 * SC) * FP + 96 + 48 + ROWTAB + (size_t)2 * S * V * V + (size_t)NGB * 16 * XP) * 4;
+    }
     if (pl.lds_gather > (size_t)kLdsBytes || pl.lds_attn > (size_t)kLdsBytes) return pl;
     if ((size_t)4 * Cout * NG > (size_t)2 * 32 * FP) return pl;   // the final reduction reuses the g tile
     pl.TF = TF;
@@ -649,9 +748,15 @@ int launch_agcn_bwd(const float *x, const float *P, const float *A_eff, const fl
     hipLaunchKernelGGL(agcn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, G, mom, (double)N * T * V, Wd, bd, Wdown, bdown, bn_w,
                        dbn_w, stats, dWd, dbd, dWdown, dbdown, dgamma, dbeta, ddgamma, ddbeta, rr, Cout);
     STGCN_LAUNCH_CHECK("agcn_bwd_finalize_kernel");
-    STGCN_HIP_CHECK(allow_lds(agcn_bwd_attn_kernel, pl.lds_attn));
-    hipLaunchKernelGGL(agcn_bwd_attn_kernel, dim3(pl.grid), dim3(NTB), pl.lds_attn, st, x, P, A_eff, hbuf, rr, part_pa, part_m, N,
-                       T, V, inter_c, pl.TF);
+    if (pl.cls == 0) {
+        STGCN_HIP_CHECK(allow_lds((agcn_bwd_attn_kernel<3, 2>), pl.lds_attn));
+        hipLaunchKernelGGL((agcn_bwd_attn_kernel<3, 2>), dim3(pl.grid), dim3(NTB), pl.lds_attn, st, x, P, A_eff, hbuf, rr, part_pa,
+                           part_m, N, T, V, inter_c, pl.TF, pl.KS);
+    } else {
+        STGCN_HIP_CHECK(allow_lds((agcn_bwd_attn_kernel<4, 7>), pl.lds_attn));
+        hipLaunchKernelGGL((agcn_bwd_attn_kernel<4, 7>), dim3(pl.grid), dim3(NTB), pl.lds_attn, st, x, P, A_eff, hbuf, rr, part_pa,
+                           part_m, N, T, V, inter_c, pl.TF, pl.KS);
+    }
     STGCN_LAUNCH_CHECK("agcn_bwd_attn_kernel");
     const int total = S * V * V + S * C1 * C1;
     hipLaunchKernelGGL((agcn_bwd_reduce_kernel<3, 3>), dim3(ceil_div(total, 32)), dim3(256), 0, st, (const float *)nullptr, part_pa,

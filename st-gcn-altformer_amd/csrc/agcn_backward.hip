@@ -106,20 +106,35 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_gather_kernel(
                 }
             }
         };
+        // the loads of block step s are issued right after step s-2 has been consumed out of the same registers: two
+        // blocks (128 KiB per CU) in flight, ~1.5 block periods ahead of their use
         f32x4 ya[4], da[4], yb[4], db[4];
         issue(ya, da, 0);
+        issue(yb, db, 1);
+        const float *xn = x + (size_t)n * CIN * plane;
+        float xr[2];                                         // x of the next chunk: HBM -> registers a chunk ahead
+        auto xfetch = [&](int ch) __attribute__((always_inline)) {
+            const int px = min(TF, T - ch * TF) * V;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + i * NTB, k = e >> 8, p = e & 255;
+                xr[i] = (k < CIN && p < px) ? xn[(size_t)k * plane + (size_t)ch * TF * V + p] : 0.f;
+            }
+        };
+        xfetch(0);
         __syncthreads();
         const float *Pn = P + (size_t)n * S * VV;
         for (int e = tid; e < S * VV; e += NTB) Ps[e] = Pn[e];
-        const float *xn = x + (size_t)n * CIN * plane;
 
         for (int ch = 0; ch < nchunks; ++ch) {
             const int t0 = ch * TF, px = min(TF, T - t0) * V;
             __syncthreads();                                 // previous chunk's h exchange fully consumed
-            for (int e = tid; e < CIN * PXMAX; e += NTB) {
-                const int k = e >> 8, p = e & 255;
-                Xs[k * FP + p] = p < px ? xn[(size_t)k * plane + (size_t)t0 * V + p] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + i * NTB, k = e >> 8, p = e & 255;
+                if (k < CIN) Xs[k * FP + p] = xr[i];
             }
+            if (ch + 1 < nchunks) xfetch(ch + 1);
             for (int e = tid; e < PXMAX; e += NTB) Fr[9 * FP + e] = e < px ? 1.f : 0.f;
             for (int e = tid; e < 3 * FP; e += NTB) Fr[13 * FP + e] = 0.f;
             __syncthreads();
@@ -182,17 +197,16 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_gather_kernel(
             };
 #pragma unroll
             for (int ob = 0; ob < NOB; ob += 2) {
-                // (the fences keep hipcc from hoisting every block's loads to the top of the unrolled loop: 285 spills)
-                issue(yb, db, ch * NOB + ob + 1);
-                __builtin_amdgcn_sched_barrier(0);
                 consume(ya, da, ob, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(ya, da, ch * NOB + ob + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
                 gram(ob, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                issue(ya, da, ch * NOB + ob + 2);
-                __builtin_amdgcn_sched_barrier(0);
                 consume(yb, db, ob + 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(yb, db, ch * NOB + ob + 3);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
                 gram(ob + 1, 1);
@@ -279,13 +293,17 @@ __global__ __launch_bounds__(256) void agcn_bwd_finalize_kernel(
     float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ ddgamma, float *__restrict__ ddbeta,
     float *__restrict__ rr /* NRR */, int Cout) {
     __shared__ double bS[256], cS[256];
+    __shared__ float Wm[256 * SC];          // Wm[o][f] = Wd[f / 3][o][f % 3]: the R sums below read it 2 * Cout * 81 times
     const double *mu = mom, *muu = mom + SC, *mx = mom + SC + 45, *mxx = mom + SC + 45 + CIN;
+    for (int e = threadIdx.x; e < Cout * SC; e += 256) {
+        const int o = e / SC, f = e - o * SC;
+        Wm[e] = Wd[((size_t)(f / CIN) * Cout + o) * CIN + (f % CIN)];
+    }
+    __syncthreads();
     for (int o = threadIdx.x; o < Cout; o += 256) {
         double w[SC], bsum = 0.0, wd[CIN];
-        for (int s = 0; s < S; ++s) {
-            bsum += (double)bd[s * Cout + o];
-            for (int k = 0; k < CIN; ++k) w[s * CIN + k] = (double)Wd[((size_t)s * Cout + o) * CIN + k];
-        }
+        for (int s = 0; s < S; ++s) bsum += (double)bd[s * Cout + o];
+        for (int f = 0; f < SC; ++f) w[f] = (double)Wm[o * SC + f];
         for (int k = 0; k < CIN; ++k) wd[k] = (double)Wdown[o * CIN + k];
         const double bdn = (double)bdown[o];
         const double *Gr = G + (size_t)o * NG;
@@ -324,19 +342,21 @@ __global__ __launch_bounds__(256) void agcn_bwd_finalize_kernel(
         }
     }
     __syncthreads();
-    if (threadIdx.x < NRR) {
-        const int t = threadIdx.x;
+    // R[f][f2] = sum_o Wm[o][f] b_m[o] Wm[o][f2],  r0[f] = sum_o Wm[o][f] (b_m[o] bm[o] + c_m[o]):  2 threads per entry
+    {
+        const int t = threadIdx.x >> 1, part = threadIdx.x & 1;
         double a = 0.0;
-        if (t < SC * SC) {
-            const int f = t / SC, f2 = t - f * SC;
-            for (int o = 0; o < Cout; ++o)
-                a += (double)Wd[((size_t)(f / CIN) * Cout + o) * CIN + (f % CIN)] * bS[o] *
-                     (double)Wd[((size_t)(f2 / CIN) * Cout + o) * CIN + (f2 % CIN)];
-        } else {
-            const int f = t - SC * SC;
-            for (int o = 0; o < Cout; ++o) a += (double)Wd[((size_t)(f / CIN) * Cout + o) * CIN + (f % CIN)] * cS[o];
+        if (t < NRR) {
+            if (t < SC * SC) {
+                const int f = t / SC, f2 = t - f * SC;
+                for (int o = part; o < Cout; o += 2) a += (double)Wm[o * SC + f] * bS[o] * (double)Wm[o * SC + f2];
+            } else {
+                const int f = t - SC * SC;
+                for (int o = part; o < Cout; o += 2) a += (double)Wm[o * SC + f] * cS[o];
+            }
         }
-        rr[t] = (float)a;
+        a += __shfl_xor(a, 1, 64);
+        if (t < NRR && part == 0) rr[t] = (float)a;
     }
 }
 

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void agcn_moments_kernel(const float *__restri
 
 // moments -> per-channel batch statistics of both BatchNorms -> (scale, shift), saved mean/invstd, running buffers
 template <int CIN, int S>
-__global__ __launch_bounds__(256) void agcn_moments_finalize_kernel(
+__global__ __launch_bounds__(1024) void agcn_moments_finalize_kernel(
     const double *__restrict__ part, int parts, double count, const float *__restrict__ Wd, const float *__restrict__ bd,
     const float *__restrict__ Wdown, const float *__restrict__ bdown, const float *__restrict__ bn_w,
     const float *__restrict__ bn_b, float *__restrict__ bn_rm, float *__restrict__ bn_rv, const float *__restrict__ dbn_w,
@@ -111,24 +111,28 @@ __global__ __launch_bounds__(256) void agcn_moments_finalize_kernel(
     float *__restrict__ save_stats /* 4*Cout + 128 floats, or NULL */, int Cout) {
     constexpr int SC = S * CIN;
     __shared__ double mom[NMOM];
-    __shared__ double sub[4][64];
+    __shared__ double sub[16][64];
     const int tid = threadIdx.x;
-    {   // 4 groups of partials per moment, then a fixed-order sum of the 4 sub-sums
+    {   // 16 groups of partials per moment (16 waves: the loads of a group are a chain of round trips), then a
+        // fixed-order sum of the 16 sub-sums
         const int i = tid & 63, grp = tid >> 6;
         double s = 0.0;
         if (i < NMOM)
-            for (int p = grp; p < parts; p += 4) s += part[(size_t)p * NMOM + i];
+            for (int p = grp; p < parts; p += 16) s += part[(size_t)p * NMOM + i];
         sub[grp][i] = s;
     }
     __syncthreads();
     if (tid < NMOM) {
-        mom[tid] = (((sub[0][tid] + sub[1][tid]) + sub[2][tid]) + sub[3][tid]) / count;
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += sub[g][tid];
+        mom[tid] = s / count;
         // the backward's moment form (agcn_backward.hip) reads the feature moments back: 63 doubles behind the 4*Cout floats
         if (save_stats) reinterpret_cast<double *>(save_stats + 4 * Cout)[tid] = mom[tid];
     }
     __syncthreads();
     const double *mu = mom, *muu = mom + SC, *mx = mom + SC + 45, *mxx = mom + SC + 45 + CIN;
-    for (int o = tid; o < Cout; o += 256) {
+    for (int o = tid; o < Cout; o += 1024) {
         double w[SC], b = 0.0;
         for (int s = 0; s < S; ++s) {
             b += (double)bd[s * Cout + o];
@@ -199,7 +203,7 @@ int launch_agcn_moments(const float *x, const float *P, double *part, const floa
     STGCN_HIP_CHECK(allow_lds((agcn_moments_kernel<3, 3>), lds));
     hipLaunchKernelGGL((agcn_moments_kernel<3, 3>), dim3(grid), dim3(256), lds, st, x, P, part, N, T, V, TF);
     STGCN_LAUNCH_CHECK("agcn_moments_kernel");
-    hipLaunchKernelGGL((agcn_moments_finalize_kernel<3, 3>), dim3(1), dim3(256), 0, st, part, grid, (double)N * T * V, Wd, bd,
+    hipLaunchKernelGGL((agcn_moments_finalize_kernel<3, 3>), dim3(1), dim3(1024), 0, st, part, grid, (double)N * T * V, Wd, bd,
                        Wdown, bdown, bn_w, bn_b, bn_rm, bn_rv, dbn_w, dbn_b, dbn_rm, dbn_rv, momentum, eps, s_m, t_m, s_d, t_d,
                        save_stats, Cout);
     STGCN_LAUNCH_CHECK("agcn_moments_finalize_kernel");

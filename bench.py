@@ -25,9 +25,10 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields:
   steady_state  a second, longer timed block in the same process (the driver's 20 steps run while the
                 clocks still ramp after idle; this block shows where the figure settles);
   alt           a short block with the exact-fp32 arithmetic (STGCN_MATH_F32) and its own roofline;
+  train         secondary: one training step of the stem (forward + backward in .train()), short block;
   cpu_baseline  the stem on torch's library CPU ops (oneDNN conv etc., oracle/stgcn_cpu_ops.py: the op mix the
                 reference itself runs), rank 0 at N=1 only; `cpu_oracle` = the einsum oracle timed the same way.
-Order inside the process: headline block, steady-state block, fp32 block, CPU legs (the GPU is never left
+Order inside the process: headline block, steady-state block, fp32 block, training block, CPU legs (the GPU is never left
 idle behind a CPU leg before a GPU measurement).
 """
 import argparse
@@ -176,12 +177,14 @@ def main():
                          "§8(f)-1 layout fusion: the loader's (N,T,V,3) batch read in place, (N,T,V,C) written")
     ap.add_argument("--steady-steps", type=int, default=300, help="length of the second timed block (0 = skip)")
     ap.add_argument("--alt-steps", type=int, default=40, help="timed steps of the exact-fp32 block (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=30,
+                    help="timed steps of the secondary training block: forward + backward of the stem in .train() (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="headline block only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=32)
     args = ap.parse_args()
     if args.no_extras:
-        args.steady_steps = args.alt_steps = 0
+        args.steady_steps = args.alt_steps = args.train_steps = 0
         args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -353,6 +356,34 @@ def main():
                            "ms_per_step": round(e3 / args.alt_steps * 1e3, 4), "value": round(v3, 1),
                            "mfma_frac": round(v3 / world * flops_clip / MFMA_PEAK["f32"], 4),
                            "roofline": roofline("f32", k3, n3, False)}
+
+    # ---- secondary: one TRAINING step of the stem (train_sttran.py:185-191 restricted to the stem) --------
+    if args.train_steps > 0 and not strong:
+        g2, t2 = build_stem(V, args.graph, args.math)
+        g2, t2 = g2.to(dev).train(), t2.to(dev).train()
+        xt = shard[0]
+        Gz = torch.randn(xt.shape[0], 128, T, V, device=dev)     # dL/dz handed in (a loss head would produce it)
+
+        def train_step():
+            for p_ in list(g2.parameters()) + list(t2.parameters()):
+                p_.grad = None
+            t2(g2(xt)).backward(Gz)
+            sd.all_reduce_grads([g2, t2])                        # bucketed RCCL all-reduce; no-op at world 1
+
+        for _ in range(5):
+            train_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            train_step()
+        fence()
+        e4 = sd.max_over_ranks(time.perf_counter() - t0, dev)
+        if rank == 0:
+            line["train"] = {"what": "forward + backward of tcn0(gcn0(x)) in .train() (batch-statistics BatchNorm, every "
+                                     "parameter gradient; dL/dz synthetic), same clips",
+                             "steps": args.train_steps, "warmup": 5, "ms_per_step": round(e4 / args.train_steps * 1e3, 4),
+                             "value": round(n_global * args.train_steps / e4, 1), "unit": "clips/s"}
+        del g2, t2, Gz
 
     if rank == 0:
         if cpu_state is not None:

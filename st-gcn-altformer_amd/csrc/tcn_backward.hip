@@ -292,7 +292,18 @@ __global__ __launch_bounds__(WG_THREADS) void tcn_wgrad_mfma_kernel(const float 
     const int KH = (K + 1) / 2;
     const int k_lo = tg * KH;                     // this wave's taps k_lo .. k_lo+KHMAX-1; those >= K are computed on real
     const int pad = (K - 1) / 2;                  // (finite) frames and dropped at the end: the tap loop has no branches
-    const int c0 = blockIdx.x * 32, o0 = blockIdx.y * 128;
+    // XCD-aware block mapping: hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2).
+    // The gridDim.x channel groups of one split read the SAME dz tile; with the natural numbering they sat on different
+    // XCDs and every one of them missed.  Re-deal: id L -> (split zi, channel group cg) such that all channel groups of a
+    // split share L % 8.  (needs gridDim.z % 8 == 0; otherwise the natural numbering)
+    int cg = blockIdx.x, zi = blockIdx.z;
+    if ((gridDim.z & 7) == 0 && !(TFM & 0x100)) {
+        const int L = blockIdx.x + gridDim.x * blockIdx.z;
+        zi = (L & 7) + 8 * (L / (8 * gridDim.x));
+        cg = (L >> 3) % gridDim.x;
+    }
+    TFM &= 0xff;                                  // (bit 8: diagnostic builds, STGCN_ABLATE=1 — natural block numbering)
+    const int c0 = cg * 32, o0 = blockIdx.y * 128;
     const int upf = Vp / 8;                       // 8-pixel units per frame
     const int FRB = TFM + 2 * KHMAX - 1;          // input frames per unit (taps 0 .. 2*KHMAX-1)
     const int unitsA = 128 * TFM * upf, unitsB = 32 * FRB * upf;
@@ -392,7 +403,7 @@ __global__ __launch_bounds__(WG_THREADS) void tcn_wgrad_mfma_kernel(const float 
     const int aoff_lo = 128 * pitchA, boff_lo = 32 * pitchB;
     const int tapb = Vp * 2;                      // bytes between consecutive taps of a B fragment
 
-    int u = blockIdx.z;
+    int u = zi;
     if (u < nunits) fetch(u);
     for (; u < nunits; u += gridDim.z) {
         __syncthreads();                          // previous unit fully consumed
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(WG_THREADS) void tcn_wgrad_mfma_kernel(const float 
 #undef D_FR
 #undef D_V0
     // D[row = o][col = c]: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float *dst = part + (size_t)blockIdx.z * Cout * Cin * K;
+    float *dst = part + (size_t)zi * Cout * Cin * K;
 #pragma unroll
     for (int kk = 0; kk < KHMAX; ++kk) {
         const int k = k_lo + kk;
@@ -580,7 +591,7 @@ int launch_tcn_wgrad(const float *dz, const float *x, float *dW, float *part, in
     do {                                                                                                               \
         STGCN_HIP_CHECK(allow_lds((tcn_wgrad_mfma_kernel<TERMS, UBN>), pl.lds));                                       \
         hipLaunchKernelGGL((tcn_wgrad_mfma_kernel<TERMS, UBN>), grid, dim3(WG_THREADS), pl.lds, st, dz, x, part, N, Cin, Cout, \
-                           T, V, K, pl.Vp, pl.pitchA, pl.pitchB, pl.tfm);                                              \
+                           T, V, K, pl.Vp, pl.pitchA, pl.pitchB, pl.tfm | ((ablate_mask() & 1) ? 0x100 : 0));                                                       \
     } while (0)
         if (math == STGCN_MATH_BF16X3) { if (pl.ub == 3) LAUNCH_WGRAD(3, 3); else LAUNCH_WGRAD(3, 5); }
         else { if (pl.ub == 3) LAUNCH_WGRAD(1, 3); else LAUNCH_WGRAD(1, 5); }

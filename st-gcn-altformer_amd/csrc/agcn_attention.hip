@@ -412,6 +412,106 @@ __global__ __launch_bounds__(256) void attention_generic_kernel(
     for (int e = tid; e < V * V; e += 256) Pn[e] = Sm[e];
 }
 
+// Generic Cin on the fp32 matrix cores (Cin % 4 == 0, inter_c % 8 == 0: every deeper TCN_GCN_unit layer of the ST-TR family,
+// model/ST_TR/ST_TR_new.py:355): one workgroup (4 waves) per (subset, clip), frame chunks through LDS;
+//   E = [Wa_s; Wb_s] x + bias      16 x 16 blocks (rows, pixels) dealt round-robin to the waves, K = Cin   (v_mfma_f32_16x16x4_f32)
+//   S[v][w] += sum_{(c,t)} a[c][t,v] b[c][t,w]   16 x 16 blocks (v, w), K = inter_c * frames; accumulators stay in registers
+// exact fp32 products, fp32 accumulation; the soft-max and the P store are the VALU kernel's.
+template <int MAXB>
+__global__ __launch_bounds__(256) void attention_generic_mfma_kernel(
+    const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
+    const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
+    float *__restrict__ P, int Cin, int T, int V, int inter_c, int S, int TC, int xsc, int xsp,
+    float *__restrict__ xcopy) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int s = blockIdx.x, n = blockIdx.y;
+    const int PXC = ((TC * V + 15) & ~15) + 4;          // row pitch: pixel blocks of 16 stay inside a row
+    float *Xs = smem;                                   // [Cin][PXC]
+    float *Es = Xs + (size_t)Cin * PXC;                 // [2*inter_c][PXC]: a rows, then b rows
+    int *rowtab = reinterpret_cast<int *>(Es + (size_t)2 * inter_c * PXC);   // (c,t) -> c*PXC + t*V, -1 = none
+    const float *xn = x + (size_t)n * Cin * T * V;
+    const float *wa = Wa + (size_t)s * inter_c * Cin, *wb = Wb + (size_t)s * inter_c * Cin;
+    const int nvb = (V + 15) / 16, nblk = nvb * nvb, R2 = 2 * inter_c, nrb = R2 / 16;
+
+    f32x4 acc[MAXB];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int tc = min(TC, T - t0), px = tc * V, npb = (px + 15) / 16;
+        __syncthreads();
+        for (int e = tid; e < Cin * px; e += 256) {
+            const int k = e / px, p = e - k * px;
+            const float xv = xn[(size_t)k * xsc + ((size_t)t0 * V + p) * xsp];
+            Xs[k * PXC + p] = xv;
+            if (xcopy && s == 0) xcopy[((size_t)n * Cin + k) * T * V + (size_t)t0 * V + p] = xv;
+        }
+        const int nk = inter_c * tc, nk4 = (nk + 3) & ~3;
+        for (int e = tid; e < nk4; e += 256) {
+            const int c = e / tc, t = e - c * tc;
+            rowtab[e] = e < nk ? c * PXC + t * V : -1;
+        }
+        __syncthreads();
+        // ---- embeddings: unit = (row block, pixel block)
+        for (int u = wave; u < nrb * npb; u += 4) {
+            const int rb = u / npb, pb = u - rb * npb;
+            const int row = rb * 16 + l16, p = pb * 16 + l16;
+            const float *wr = row < inter_c ? wa + (size_t)row * Cin : wb + (size_t)(row - inter_c) * Cin;
+            f32x4 e4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < Cin / 4; ++ks) {
+                const int c = 4 * ks + lq;
+                const float a = wr[c];
+                const float b = p < px ? Xs[c * PXC + p] : 0.f;
+                e4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, e4, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rb * 16 + 4 * lq + i;
+                const float bias = r < inter_c ? ba[s * inter_c + r] : bb[s * inter_c + r - inter_c];
+                Es[r * PXC + p] = e4[i] + bias;                         // (p < pitch: pixel blocks stay inside the row)
+            }
+        }
+        __syncthreads();
+        // ---- Gram: block = (v block, w block)
+        const float *As = Es, *Bs = Es + (size_t)inter_c * PXC;
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            const int blk = wave + 4 * i;
+            if (blk < nblk) {
+                const int v = (blk / nvb) * 16 + l16, w = (blk % nvb) * 16 + l16;
+                for (int ks = 0; ks < nk4 / 4; ++ks) {
+                    const int off = rowtab[4 * ks + lq];
+                    const float a = (off >= 0 && v < V) ? As[off + v] : 0.f;
+                    const float b = (off >= 0 && w < V) ? Bs[off + w] : 0.f;
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float *Sm = smem;  // [V][V]
+    const float denom = (float)(inter_c * T);
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int blk = wave + 4 * i;
+        if (blk < nblk) {
+            const int w = (blk % nvb) * 16 + l16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = (blk / nvb) * 16 + 4 * lq + j;
+                if (v < V && w < V) Sm[v * V + w] = acc[i][j] / denom;
+            }
+        }
+    }
+    __syncthreads();
+    softmax_columns(Sm, A_eff, 1, V, s, tid, 256);
+    __syncthreads();
+    float *Pn = P + ((size_t)n * S + s) * V * V;
+    for (int e = tid; e < V * V; e += 256) Pn[e] = Sm[e];
+}
+
 }  // namespace
 
 // true when launch_attention can also emit the (N, T*V, 16) feature tensor (folded kernel, Cin = 3, S = 3)
@@ -507,7 +607,32 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
         STGCN_LAUNCH_CHECK("attention_folded_kernel");
         return STGCN_OK;
     }
-    // generic path
+    // generic path: on the matrix cores when the shapes tile (every TCN_GCN_unit layer of the reference does)
+    if (Cin % 4 == 0 && inter_c % 8 == 0 && V <= 64 && !(ablate_mask() & 2048)) {   // (diagnostic builds: 2048 = the VALU kernel)
+        const size_t budget = (size_t)96 * 1024 / 4;
+        int TC = (int)(budget / ((size_t)V * (Cin + 2 * inter_c)));
+        if (TC > T) TC = T;
+        if (TC < 1) TC = 1;
+        const int PXC = ((TC * V + 15) & ~15) + 4;
+        size_t fl = (size_t)PXC * (Cin + 2 * inter_c) + (size_t)inter_c * TC + 4;
+        if (fl < (size_t)V * V) fl = (size_t)V * V;
+        const size_t lds = fl * 4;
+        if (lds <= (size_t)kLdsBytes) {
+            const int nvb = (V + 15) / 16, per_wave = ceil_div(nvb * nvb, 4);
+#define LAUNCH_GMFMA(MB)                                                                                     \
+    do {                                                                                                     \
+        STGCN_HIP_CHECK(allow_lds(attention_generic_mfma_kernel<MB>, lds));                                  \
+        hipLaunchKernelGGL(attention_generic_mfma_kernel<MB>, dim3(S, N), dim3(256), lds, st, x, A_eff, Wa, ba, Wb, bb, P, \
+                           Cin, T, V, inter_c, S, TC, xsc, xsp, xcopy);                                      \
+    } while (0)
+            if (per_wave <= 1) LAUNCH_GMFMA(1);
+            else if (per_wave <= 3) LAUNCH_GMFMA(3);
+            else LAUNCH_GMFMA(4);
+#undef LAUNCH_GMFMA
+            STGCN_LAUNCH_CHECK("attention_generic_mfma_kernel");
+            return STGCN_OK;
+        }
+    }
     const int maxit = ceil_div(V * V, 256);
     if (maxit > 16) return fail(STGCN_ERR_UNSUPPORTED, "attention: V=%d too large (max 64)", V);
     const size_t budget = (size_t)96 * 1024 / 4;

@@ -770,6 +770,35 @@ def test_unit_agcn_backward_vs_oracle(N, T, V, cout, dev):
     _compare_grads(_agcn_module_grads(gcn), ref, 1e-4)
 
 
+@pytest.mark.parametrize("cin,cout,N,T,V,layout", [
+    (64, 64, 2, 180, 22, "nctv"),     # TCN_GCN_unit(64, 64) at the reference's frame count: 17 frame chunks
+    (64, 128, 3, 37, 22, "nctv"),     # ragged last chunk
+    (128, 128, 2, 90, 25, "nctv"),    # after the first stride-2 unit, odd joint count
+    (256, 256, 1, 45, 22, "nctv"),    # last stage: inter_c = 64, two-frame chunks
+    (64, 64, 2, 9, 46, "nctv"),       # two-hand graph: 3 x 3 blocks of the Gram
+    (32, 64, 2, 5, 7, "nctv"),        # one block, mostly padding
+    (64, 64, 1, 1, 22, "nctv"),       # a single frame
+    (64, 64, 2, 30, 64, "nctv"),      # widest graph the attention kernels take
+    (64, 64, 2, 23, 22, "ntvc")])     # channels-last input view
+def test_generic_attention_on_matrix_cores_vs_oracle(cin, cout, N, T, V, layout, dev):
+    """the adaptive adjacency of the deeper unit_agcn layers (model/unit_agcn.py:73-85 with C_in = 64..256:
+    embeddings, Gram over (inter_c, T), column soft-max) runs on the fp32 matrix cores; P and the module output against the
+    fp64 oracle at 1e-4."""
+    from oracle import stgcn_oracle as so
+    gcn, _, gp, _, gen = _random_stem(V, None, 3000 + cin + cout + T + V, dev, cin=cin, c=cout)
+    x = torch.randn(N, cin, T, V, generator=gen)
+    aux = {}
+    yr = so.agcn_forward(x.double(), gp.to(torch.float64), aux=aux)
+    P_ref = aux["P"]
+    xg = x.to(dev)
+    if layout == "ntvc":
+        xg = xg.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    with torch.no_grad():
+        y = gcn(xg)
+    parity_gate(gcn.last_attention, P_ref, 1e-4, "P")
+    parity_gate(y, yr, 1e-4, "y")
+
+
 @pytest.mark.parametrize("cin,cout,N,T,V,want_dx", [
     (64, 64, 2, 12, 22, True),      # TCN_GCN_unit(64, 64): identity residual (unit_agcn.py:57-58), input gradient
     (64, 128, 2, 10, 22, True),     # TCN_GCN_unit(64, 128): conv + BatchNorm residual, input gradient

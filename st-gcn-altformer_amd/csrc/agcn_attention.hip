@@ -412,104 +412,160 @@ __global__ __launch_bounds__(256) void attention_generic_kernel(
     for (int e = tid; e < V * V; e += 256) Pn[e] = Sm[e];
 }
 
-// Generic Cin on the fp32 matrix cores (Cin % 4 == 0, inter_c % 8 == 0: every deeper TCN_GCN_unit layer of the ST-TR family,
-// model/ST_TR/ST_TR_new.py:355): one workgroup (4 waves) per (subset, clip), frame chunks through LDS;
-//   E = [Wa_s; Wb_s] x + bias      16 x 16 blocks (rows, pixels) dealt round-robin to the waves, K = Cin   (v_mfma_f32_16x16x4_f32)
-//   S[v][w] += sum_{(c,t)} a[c][t,v] b[c][t,w]   16 x 16 blocks (v, w), K = inter_c * frames; accumulators stay in registers
-// exact fp32 products, fp32 accumulation; the soft-max and the P store are the VALU kernel's.
-template <int MAXB>
-__global__ __launch_bounds__(256) void attention_generic_mfma_kernel(
+// Generic Cin on the fp32 matrix cores (Cin % 4 == 0, inter_c = 8, 16, 32 or 64: every deeper TCN_GCN_unit layer of the
+// ST-TR family, model/ST_TR/ST_TR_new.py:355).  One workgroup (8 waves) per CLIP, x streamed once in frame chunks through
+// LDS and shared by the three subsets; per chunk and subset
+//   E = [Wa_s; Wb_s] x + bias      16 x 16 blocks (rows, pixels), K = Cin: a wave owns one row block, keeps its weight fragments
+//                                  in registers (loaded once per chunk and subset, KS = Cin/4 of them) and walks pixel blocks
+//   S_s[v][w] += sum_{(c,t)} a[c][t,v] b[c][t,w]   16 x 16 blocks (v, w) x K parts dealt to the waves, K = inter_c * frames,
+//                                  accumulators in registers across the chunks
+// (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation), then the column soft-max of the VALU kernel.
+// Row pitch of the LDS tiles = 16 mod 64 floats: the four k rows of a B fragment read land on disjoint banks.
+template <int KS, int MAXB>
+__global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
     const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
     const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
-    float *__restrict__ P, int Cin, int T, int V, int inter_c, int S, int TC, int xsc, int xsp,
+    float *__restrict__ P, int Cin, int T, int V, int inter_c, int S, int TC, int PXC, int xsc, int xsp,
     float *__restrict__ xcopy) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, lq = lane >> 4;
-    const int s = blockIdx.x, n = blockIdx.y;
-    const int PXC = ((TC * V + 15) & ~15) + 4;          // row pitch: pixel blocks of 16 stay inside a row
+    const int n = blockIdx.x;
     float *Xs = smem;                                   // [Cin][PXC]
-    float *Es = Xs + (size_t)Cin * PXC;                 // [2*inter_c][PXC]: a rows, then b rows
-    int *rowtab = reinterpret_cast<int *>(Es + (size_t)2 * inter_c * PXC);   // (c,t) -> c*PXC + t*V, -1 = none
+    float *Es = Xs + (size_t)Cin * PXC;                 // [2*inter_c][PXC]: a rows, then b rows (one subset at a time)
     const float *xn = x + (size_t)n * Cin * T * V;
-    const float *wa = Wa + (size_t)s * inter_c * Cin, *wb = Wb + (size_t)s * inter_c * Cin;
     const int nvb = (V + 15) / 16, nblk = nvb * nvb, R2 = 2 * inter_c, nrb = R2 / 16;
+    const int R8 = nrb < 8 ? nrb : 8, pstep = 8 / R8;   // waves per row block = pstep
+    const int KSP = nblk >= 8 ? 1 : 8 / nblk;           // K parts of a Gram block (nblk = 1, 4: 8, 2)
+    const int nunits = nblk * KSP;
+    const int ks_n = Cin / 4;
+    const int icm = inter_c - 1, icl = 31 - __builtin_clz(inter_c);
 
-    f32x4 acc[MAXB];
+    f32x4 acc[3][MAXB];
 #pragma unroll
-    for (int i = 0; i < MAXB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) acc[s][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int tc = min(TC, T - t0), px = tc * V, npb = (px + 15) / 16;
         __syncthreads();
-        for (int e = tid; e < Cin * px; e += 256) {
-            const int k = e / px, p = e - k * px;
-            const float xv = xn[(size_t)k * xsc + ((size_t)t0 * V + p) * xsp];
-            Xs[k * PXC + p] = xv;
-            if (xcopy && s == 0) xcopy[((size_t)n * Cin + k) * T * V + (size_t)t0 * V + p] = xv;
-        }
-        const int nk = inter_c * tc, nk4 = (nk + 3) & ~3;
-        for (int e = tid; e < nk4; e += 256) {
-            const int c = e / tc, t = e - c * tc;
-            rowtab[e] = e < nk ? c * PXC + t * V : -1;
-        }
-        __syncthreads();
-        // ---- embeddings: unit = (row block, pixel block)
-        for (int u = wave; u < nrb * npb; u += 4) {
-            const int rb = u / npb, pb = u - rb * npb;
-            const int row = rb * 16 + l16, p = pb * 16 + l16;
-            const float *wr = row < inter_c ? wa + (size_t)row * Cin : wb + (size_t)(row - inter_c) * Cin;
-            f32x4 e4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int ks = 0; ks < Cin / 4; ++ks) {
-                const int c = 4 * ks + lq;
-                const float a = wr[c];
-                const float b = p < px ? Xs[c * PXC + p] : 0.f;
-                e4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, e4, 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = rb * 16 + 4 * lq + i;
-                const float bias = r < inter_c ? ba[s * inter_c + r] : bb[s * inter_c + r - inter_c];
-                Es[r * PXC + p] = e4[i] + bias;                         // (p < pitch: pixel blocks stay inside the row)
+        for (int k = wave; k < Cin; k += 8) {            // a wave per channel row, lanes along the pixels: no index division
+            const float *xr = xn + (size_t)k * xsc + (size_t)t0 * V * xsp;
+            for (int p = lane; p < px; p += 64) {
+                const float xv = xr[(size_t)p * xsp];
+                Xs[k * PXC + p] = xv;
+                if (xcopy) xcopy[((size_t)n * Cin + k) * T * V + (size_t)t0 * V + p] = xv;
             }
         }
-        __syncthreads();
-        // ---- Gram: block = (v block, w block)
-        const float *As = Es, *Bs = Es + (size_t)inter_c * PXC;
+        // contraction index of the Gram: idx = t * inter_c + c (inter_c is a power of two: shifts, no table)
+        const int nk = inter_c * tc;
+        const int kpp = ((nk / 4 + KSP - 1) / KSP);     // k-steps per K part  (inter_c % 8 == 0: nk % 4 == 0)
 #pragma unroll
-        for (int i = 0; i < MAXB; ++i) {
-            const int blk = wave + 4 * i;
-            if (blk < nblk) {
-                const int v = (blk / nvb) * 16 + l16, w = (blk % nvb) * 16 + l16;
-                for (int ks = 0; ks < nk4 / 4; ++ks) {
-                    const int off = rowtab[4 * ks + lq];
-                    const float a = (off >= 0 && v < V) ? As[off + v] : 0.f;
-                    const float b = (off >= 0 && w < V) ? Bs[off + w] : 0.f;
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        for (int s = 0; s < 3; ++s) {
+            if (s < S) {
+                __syncthreads();                        // Xs ready; the previous subset's Gram is done with Es
+                // ---- embeddings
+                for (int rb = wave % R8; rb < nrb; rb += R8) {
+                    const int row = rb * 16 + l16;
+                    const float *wr = row < inter_c ? Wa + ((size_t)s * inter_c + row) * Cin
+                                                    : Wb + ((size_t)s * inter_c + row - inter_c) * Cin;
+                    float wf[KS];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) wf[ks] = ks < ks_n ? wr[4 * ks + lq] : 0.f;
+                    float bias[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = rb * 16 + 4 * lq + i;
+                        bias[i] = r < inter_c ? ba[s * inter_c + r] : bb[s * inter_c + r - inter_c];
+                    }
+                    for (int pb = wave / R8; pb < npb; pb += pstep) {
+                        const int p = pb * 16 + l16;
+                        const float *xb = Xs + lq * PXC + (p < px ? p : 0);
+                        const bool pok = p < px;
+                        f32x4 e4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            if (ks < ks_n) {
+                                const float b = pok ? xb[(size_t)4 * ks * PXC] : 0.f;
+                                e4 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ks], b, e4, 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) Es[(rb * 16 + 4 * lq + i) * PXC + p] = e4[i] + bias[i];
+                    }
+                }
+                __syncthreads();
+                // ---- Gram: unit = (block, K part)
+                const float *As = Es, *Bs = Es + (size_t)inter_c * PXC;
+#pragma unroll
+                for (int i = 0; i < MAXB; ++i) {
+                    const int unit = wave + 8 * i;
+                    if (unit < nunits) {
+                        const int blk = unit / KSP, kq = unit - blk * KSP;
+                        const int v = (blk / nvb) * 16 + l16, w = (blk % nvb) * 16 + l16;
+                        const int k1 = min((kq + 1) * kpp, nk / 4);
+                        const int va = v < V ? v : 0, wa_ = w < V ? w : 0;
+                        const float vm = v < V ? 1.f : 0.f, wm = w < V ? 1.f : 0.f;   // (rows / columns beyond V: zeroed operands)
+                        int ks = kq * kpp;
+                        for (; ks + 4 <= k1; ks += 4) {      // four k-steps per trip: eight LDS reads in flight, then the MFMAs
+                            float a4[4], b4[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int idx = 4 * (ks + q) + lq;
+                                const int off = (idx & icm) * PXC + (idx >> icl) * V;
+                                a4[q] = As[off + va] * vm;
+                                b4[q] = Bs[off + wa_] * wm;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q], b4[q], acc[s][i], 0, 0, 0);
+                        }
+                        for (; ks < k1; ++ks) {
+                            const int idx = 4 * ks + lq;
+                            const int off = (idx & icm) * PXC + (idx >> icl) * V;
+                            acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[off + va] * vm, Bs[off + wa_] * wm, acc[s][i], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- the K parts of a block meet in LDS (fixed order), soft-max, store
+    __syncthreads();
+    const int VV = V * V;
+    float *parts = smem;                                // [S][KSP][V][V]
+    float *Sm = parts + (size_t)S * KSP * VV;           // [S][V][V]
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s < S) {
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                const int unit = wave + 8 * i;
+                if (unit < nunits) {
+                    const int blk = unit / KSP, kq = unit - blk * KSP;
+                    const int w = (blk % nvb) * 16 + l16;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int v = (blk / nvb) * 16 + 4 * lq + j;
+                        if (v < V && w < V) parts[((size_t)s * KSP + kq) * VV + v * V + w] = acc[s][i][j];
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    float *Sm = smem;  // [V][V]
     const float denom = (float)(inter_c * T);
-#pragma unroll
-    for (int i = 0; i < MAXB; ++i) {
-        const int blk = wave + 4 * i;
-        if (blk < nblk) {
-            const int w = (blk % nvb) * 16 + l16;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int v = (blk / nvb) * 16 + 4 * lq + j;
-                if (v < V && w < V) Sm[v * V + w] = acc[i][j] / denom;
-            }
-        }
+    for (int e = tid; e < S * VV; e += 512) {
+        const int s = e / VV, vw = e - s * VV;
+        float a = 0.f;
+        for (int kq = 0; kq < KSP; ++kq) a += parts[((size_t)s * KSP + kq) * VV + vw];
+        Sm[e] = a / denom;
     }
     __syncthreads();
-    softmax_columns(Sm, A_eff, 1, V, s, tid, 256);
+    softmax_columns(Sm, A_eff, S, V, 0, tid, 512);
     __syncthreads();
-    float *Pn = P + ((size_t)n * S + s) * V * V;
-    for (int e = tid; e < V * V; e += 256) Pn[e] = Sm[e];
+    float *Pn = P + (size_t)n * S * VV;
+    for (int e = tid; e < S * VV; e += 512) Pn[e] = Sm[e];
 }
 
 }  // namespace
@@ -608,26 +664,33 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
         return STGCN_OK;
     }
     // generic path: on the matrix cores when the shapes tile (every TCN_GCN_unit layer of the reference does)
-    if (Cin % 4 == 0 && inter_c % 8 == 0 && V <= 64 && !(ablate_mask() & 2048)) {   // (diagnostic builds: 2048 = the VALU kernel)
-        const size_t budget = (size_t)96 * 1024 / 4;
+    const bool ic_ok = inter_c == 8 || inter_c == 16 || inter_c == 32 || inter_c == 64;
+    if (Cin % 4 == 0 && Cin <= 256 && ic_ok && S <= 3 && V <= 64 && !(ablate_mask() & 2048)) {   // (diagnostic builds: 2048 = the VALU kernel)
+        const size_t budget = (size_t)128 * 1024 / 4;
         int TC = (int)(budget / ((size_t)V * (Cin + 2 * inter_c)));
         if (TC > T) TC = T;
         if (TC < 1) TC = 1;
-        const int PXC = ((TC * V + 15) & ~15) + 4;
+        auto pitch = [&](int tc) { return ((tc * V + 63) & ~63) + 16; };
+        while (TC > 1 && (size_t)pitch(TC) * (Cin + 2 * inter_c) > budget) --TC;
+        const int PXC = pitch(TC);
+        const int nvb = (V + 15) / 16, nblk = nvb * nvb, KSP = nblk >= 8 ? 1 : 8 / nblk;
         size_t fl = (size_t)PXC * (Cin + 2 * inter_c) + (size_t)inter_c * TC + 4;
-        if (fl < (size_t)V * V) fl = (size_t)V * V;
+        const size_t tail = (size_t)S * (KSP + 1) * V * V;
+        if (fl < tail) fl = tail;
         const size_t lds = fl * 4;
         if (lds <= (size_t)kLdsBytes) {
-            const int nvb = (V + 15) / 16, per_wave = ceil_div(nvb * nvb, 4);
-#define LAUNCH_GMFMA(MB)                                                                                     \
+            const int per_wave = ceil_div(nblk * KSP, 8), ks = Cin / 4;
+#define LAUNCH_GMFMA(KSN, MB)                                                                                \
     do {                                                                                                     \
-        STGCN_HIP_CHECK(allow_lds(attention_generic_mfma_kernel<MB>, lds));                                  \
-        hipLaunchKernelGGL(attention_generic_mfma_kernel<MB>, dim3(S, N), dim3(256), lds, st, x, A_eff, Wa, ba, Wb, bb, P, \
-                           Cin, T, V, inter_c, S, TC, xsc, xsp, xcopy);                                      \
+        STGCN_HIP_CHECK(allow_lds((attention_generic_mfma_kernel<KSN, MB>), lds));                           \
+        hipLaunchKernelGGL((attention_generic_mfma_kernel<KSN, MB>), dim3(N), dim3(512), lds, st, x, A_eff, Wa, ba, Wb, bb, P, \
+                           Cin, T, V, inter_c, S, TC, PXC, xsc, xsp, xcopy);                                 \
     } while (0)
-            if (per_wave <= 1) LAUNCH_GMFMA(1);
-            else if (per_wave <= 3) LAUNCH_GMFMA(3);
-            else LAUNCH_GMFMA(4);
+            if (per_wave <= 1) {
+                if (ks <= 16) LAUNCH_GMFMA(16, 1); else if (ks <= 32) LAUNCH_GMFMA(32, 1); else LAUNCH_GMFMA(64, 1);
+            } else {
+                if (ks <= 16) LAUNCH_GMFMA(16, 2); else if (ks <= 32) LAUNCH_GMFMA(32, 2); else LAUNCH_GMFMA(64, 2);
+            }
 #undef LAUNCH_GMFMA
             STGCN_LAUNCH_CHECK("attention_generic_mfma_kernel");
             return STGCN_OK;

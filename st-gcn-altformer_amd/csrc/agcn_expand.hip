@@ -243,6 +243,139 @@ __global__ __launch_bounds__(256) void agcn_expand_generic_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generic C_in / C_out on the fp32 matrix cores (C_in, C_out multiples of 16, 3 subsets: every deeper TCN_GCN_unit
+// layer, model/ST_TR/ST_TR_new.py:355).  The old generic kernel recomputed the aggregation per block of 32 output channels
+// on plain FMAs: 8.2 ms at 64 -> 64 and 82 ms at 128 -> 128 channels (256 clips, T = 180).
+//
+// Workgroup (8 waves) = one clip x one frame chunk of <= 256 pixels x ALL output channels; the input channels go by in
+// chunks of 16.  Per chunk:
+//   x rows -> LDS;  u_s[c][t,w] = sum_v x[c][t,v] P_s[v,w] as 16 x 16 x (V) blocks (block = (subset, frame, w block): the
+//   16 rows of a block are the chunk's 16 channels, so no row table is needed) -> LDS rows (s, c);
+//   out[o][p] += sum_kk A[o][kk] B[kk][p],  kk = (s, c) for the three subsets then (x, c) for the conv residual:
+//   A = Wd_s * bn_scale / Wdown * down_scale (the BatchNorm scales folded in at fragment load: ONE accumulator serves both
+//   branches), fragments in registers per chunk, B = the LDS rows (pitch = 16 mod 64 floats: conflict-free).
+// Epilogue: + folded constants (+ x for the identity residual), ReLU unless raw, 64-byte segments per channel row.
+// v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation (same 1e-4 gate as every fp32 path).
+template <int NOW /* o-blocks per wave */, int NPB /* pixel blocks per wave */>
+__global__ __launch_bounds__(512) void agcn_expand_mfma_kernel(
+    const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ Wd,
+    const float *__restrict__ bd, const float *__restrict__ Wdown, const float *__restrict__ bdown,
+    const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
+    const float *__restrict__ down_scale, const float *__restrict__ down_shift,
+    float *__restrict__ y, int Cin, int Cout, int T, int V, int TF, int PXP, int mode) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int n = blockIdx.y, t0 = blockIdx.x * TF;
+    const int tf = min(TF, T - t0), px = tf * V;
+    const int VV = V * V, nvb = (V + 15) / 16;
+    float *Ps = smem;                       // [3][V][V]
+    float *Ub = Ps + 3 * VV;                // [64][PXP]: rows (s, c) for s = 0..2, then the x rows (c)
+    float *Xs = Ub + 48 * PXP;
+    const bool identity = (Wdown == nullptr);
+    const int KK = identity ? 48 : 64;      // contraction rows per chunk
+    const int nob = Cout / 16;
+    // wave -> its NOW o-blocks (stride 8 / wpo) and its NPB pixel blocks
+    const int wpo = nob >= 8 ? 1 : 8 / nob;                 // waves per o-block
+    const int ob0 = wave / wpo, pb0 = wave % wpo;           // first o-block (step 8 / wpo = nob when wpo > 1), first pixel block
+    const int ostep = 8 / wpo;
+    const size_t plane = (size_t)T * V;
+    const float *Pn = P + (size_t)n * 3 * VV;
+    for (int e = tid; e < 3 * VV; e += 512) Ps[e] = Pn[e];
+    const float *xn = x + (size_t)n * Cin * plane + (size_t)t0 * V;
+
+    f32x4 acc[NOW][NPB];
+#pragma unroll
+    for (int a = 0; a < NOW; ++a)
+#pragma unroll
+        for (int b = 0; b < NPB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c0 = 0; c0 < Cin; c0 += 16) {
+        __syncthreads();                                    // previous chunk's rows fully consumed (and Ps loaded)
+        for (int r = wave; r < 16; r += 8) {                // a wave per channel row, lanes along the pixels
+            const float *xr = xn + (size_t)(c0 + r) * plane;
+            for (int p = lane; p < 256; p += 64) Xs[r * PXP + p] = p < px ? xr[p] : 0.f;
+        }
+        __syncthreads();
+        // ---- aggregation blocks (s, t, w block): rows = the 16 channels
+        for (int u = wave; u < 3 * tf * nvb; u += 8) {
+            const int s = u / (tf * nvb), rem = u - s * tf * nvb, t = rem / nvb, wb = rem - t * nvb;
+            const int w = wb * 16 + l16;
+            f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *xr = Xs + l16 * PXP + t * V;
+            const float *pr = Ps + s * VV + (w < V ? w : 0);
+            for (int ks = 0; ks < (V + 3) / 4; ++ks) {
+                const int v = 4 * ks + lq;
+                const float av = v < V ? xr[v] : 0.f;
+                const float bv = (v < V && w < V) ? pr[v * V] : 0.f;
+                a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, a4, 0, 0, 0);
+            }
+            if (w < V) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Ub[(s * 16 + 4 * lq + i) * PXP + t * V + w] = a4[i];
+            }
+        }
+        // ---- this wave's weight fragments of the chunk (BatchNorm scales folded in)
+        float wf[NOW][16];
+#pragma unroll
+        for (int a = 0; a < NOW; ++a) {
+            const int o = (ob0 + a * ostep) * 16 + l16;
+            const float sm_ = bn_scale[o], sd_ = identity ? 0.f : down_scale[o];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int kk = 4 * ks + lq, s = kk >> 4, c = c0 + (kk & 15);
+                wf[a][ks] = s < 3 ? Wd[((size_t)s * Cout + o) * Cin + c] * sm_ : (identity ? 0.f : Wdown[(size_t)o * Cin + c] * sd_);
+            }
+        }
+        __syncthreads();
+        // ---- out += A B
+#pragma unroll
+        for (int b = 0; b < NPB; ++b) {
+            const int pb = pb0 + b * wpo;
+            if (pb * 16 < px) {
+                const float *br = Ub + lq * PXP + pb * 16 + l16;
+                float bf[16];
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) bf[ks] = (4 * ks < KK) ? br[(size_t)4 * ks * PXP] : 0.f;
+#pragma unroll
+                for (int a = 0; a < NOW; ++a)
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks)
+                        if (4 * ks < KK) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[a][ks], bf[ks], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue
+    float *yn = y + (size_t)n * Cout * plane + (size_t)t0 * V;
+#pragma unroll
+    for (int a = 0; a < NOW; ++a) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = (ob0 + a * ostep) * 16 + 4 * lq + i;
+            float cst = bn_shift[o];
+            {
+                float b = 0.f;
+                for (int s = 0; s < 3; ++s) b += bd[s * Cout + o];
+                cst = fmaf(bn_scale[o], b, cst);
+            }
+            if (!identity) cst += fmaf(down_scale[o], bdown[o], down_shift[o]);
+#pragma unroll
+            for (int b = 0; b < NPB; ++b) {
+                const int p = (pb0 + b * wpo) * 16 + l16;
+                if (p < px) {
+                    float val = acc[a][b][i] + cst;
+                    if (identity && !(mode & 2)) val += xn[(size_t)o * plane + p];   // mode bit 1: leave the residual out
+                    yn[(size_t)o * plane + p] = (mode & 1) ? val : fmaxf(val, 0.f);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int launch_agcn_expand(const float *x, const float *P, const float *Wd, const float *bd,
@@ -280,7 +413,28 @@ int launch_agcn_expand(const float *x, const float *P, const float *Wd, const fl
             return STGCN_OK;
         }
     }
-    // generic
+    // generic shapes on the matrix cores
+    if (S == 3 && Cin % 16 == 0 && Cout % 16 == 0 && V <= 64 && (Cout == 64 || Cout == 128 || Cout == 256) && !(ablate_mask() & 4096)) {
+        int TF = 256 / V;
+        if (TF < 1) TF = 1;
+        if (TF > T) TF = T;
+        const int PXP = 256 + 16;
+        const size_t lds = ((size_t)3 * V * V + (size_t)64 * PXP) * 4;
+        const dim3 grid(ceil_div(T, TF), N);
+#define LAUNCH_EXP(NOW_, NPB_)                                                                                         \
+    do {                                                                                                               \
+        STGCN_HIP_CHECK(allow_lds((agcn_expand_mfma_kernel<NOW_, NPB_>), lds));                                        \
+        hipLaunchKernelGGL((agcn_expand_mfma_kernel<NOW_, NPB_>), grid, dim3(512), lds, st, x, P, Wd, bd, Wdown, bdown, bn_scale, \
+                           bn_shift, down_scale, down_shift, y, Cin, Cout, T, V, TF, PXP, mode);                      \
+    } while (0)
+        if (Cout == 64) LAUNCH_EXP(1, 8);          // 4 o-blocks x 2 waves each: 8 of the 16 pixel blocks per wave
+        else if (Cout == 128) LAUNCH_EXP(1, 16);   // 8 o-blocks, one wave each
+        else LAUNCH_EXP(2, 16);                    // 16 o-blocks, two per wave
+#undef LAUNCH_EXP
+        STGCN_LAUNCH_CHECK("agcn_expand_mfma_kernel");
+        return STGCN_OK;
+    }
+    // generic, any shape (plain FMAs)
     const size_t budget = (size_t)96 * 1024 / 4;
     const size_t pfl = (size_t)S * V * V;
     if (pfl + (size_t)Cin * V > (size_t)kLdsBytes / 4)

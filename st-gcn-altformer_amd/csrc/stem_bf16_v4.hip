@@ -710,6 +710,7 @@ __global__ __launch_bounds__(NT4) void tcn_bf16_v4_kernel(
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int ob = cg * 128 + (wm * 2 + m) * 32;
+                    if (ob >= C) continue;                // padded rows of a 64-channel layer (wave-uniform)
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         const float4 sh4 = *reinterpret_cast<const float4 *>(shift + ob + 8 * gq + 4 * hh);
@@ -740,6 +741,7 @@ __global__ __launch_bounds__(NT4) void tcn_bf16_v4_kernel(
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int ob = cg * 128 + (wm * 2 + m) * 32;
+                    if (ob >= C) continue;                // padded rows of a 64-channel layer (wave-uniform)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int cr = (r & 3) + 8 * (r >> 2) + 4 * (lane_e >> 5);
@@ -840,7 +842,7 @@ struct T4Plan {
 };
 
 inline bool plan_t4(int Cin, int Cout, int T, int V, int K, int stride, int terms, T4Plan &pl) {
-    if (K != KT4 || stride != 1 || Cout % 128 != 0 || Cin % CCB != 0 || T < 1) return false;
+    if (K != KT4 || stride != 1 || (Cout % 128 != 0 && Cout != 64) || Cin % CCB != 0 || T < 1) return false;
     int dt = ceil_div(NP4 - 1, V);
     if (dt > T - 1) dt = T - 1;
     const int span = (dt + K) * V;
@@ -879,7 +881,7 @@ int launch_tcn_v4(const float *x, const void *Wp, const float *shift, void *y, i
     STGCN_HIP_CHECK(hipGetDevice(&dev));
     STGCN_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntiles = N * pl.tiles_per_clip;
-    const dim3 grid(ntiles < num_cu ? ntiles : num_cu, Cout / 128, 1);
+    const dim3 grid(ntiles < num_cu ? ntiles : num_cu, ceil_div(Cout, 128), 1);
 #define LAUNCH_T4(TERMS, B)                                                                                       \
     do {                                                                                                          \
         auto kern = tcn_bf16_v4_kernel<TERMS, B>;                                                                 \

@@ -39,10 +39,12 @@ constexpr int NT = 256;   // threads per workgroup
 
 // weight packing: Wp (bf16) index (((((mb*nch+ch)*K+tap)*2+img)*64+lane)*8+j
 //   o = mb*32 + (lane&31), c = ch*16 + 8*(lane>>5) + j, value = split(scale[o]*W[o][c][tap])[img]
+// (Cout = 64 is packed as 128 rows, the upper 64 zero: the 128-channel tiles then serve it, half of their MFMAs idle —
+//  still an order of magnitude ahead of the plain-FMA kernel; the epilogues skip rows >= Cout)
 __global__ void tcn_pack_bf16_kernel(const float *__restrict__ W, const float *__restrict__ scale,
-                                     unsigned short *__restrict__ Wp, int Cin, int Cout, int K) {
+                                     unsigned short *__restrict__ Wp, int Cin, int Cout, int CoutP, int K) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (weight, img)
-    if (e >= (size_t)Cout * Cin * K * 2) return;
+    if (e >= (size_t)CoutP * Cin * K * 2) return;
     const int j = (int)(e & 7);
     const int lane = (int)((e >> 3) & 63);
     size_t r = e >> 9;
@@ -55,7 +57,7 @@ __global__ void tcn_pack_bf16_kernel(const float *__restrict__ W, const float *_
     const int mb = (int)(r / nch);
     const int o = mb * 32 + (lane & 31);
     const int c = ch * CCB + 8 * (lane >> 5) + j;
-    const float w = scale[o] * W[((size_t)o * Cin + c) * K + tap];
+    const float w = o < Cout ? scale[o] * W[((size_t)o * Cin + c) * K + tap] : 0.f;
     const unsigned h = pack_bf16x2(w, 0.f) & 0xffffu;
     const unsigned l = pack_bf16x2(w - bf16_lo_to_f32(h), 0.f) & 0xffffu;
     Wp[e] = (unsigned short)(img ? l : h);
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(NT) void tcn_mfma_bf16_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = (mb0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (o >= Cout) continue;                      // padded rows of a 64-channel layer
             const float sh = shift[o];
             const size_t base = ((size_t)n * Cout + o) * ppc;
 #pragma unroll
@@ -550,7 +553,7 @@ struct Bf16Plan {
 };
 
 inline bool plan_bf16(int Cin, int Cout, int V, int K, int stride, int Tout, int terms, Bf16Plan &pl) {
-    if (Cin % CCB != 0 || Cout % 128 != 0) return false;
+    if (Cin % CCB != 0 || (Cout % 128 != 0 && Cout != 64)) return false;
     const int rows = rows_needed(V, K, stride, Tout);
     const int jpr = ceil_div(rows - 1, NT);
     if (jpr > 3) return false;
@@ -566,7 +569,7 @@ inline bool plan_bf16(int Cin, int Cout, int V, int K, int stride, int Tout, int
 template <int JPR, int TERMS, int KT>
 int launch_variant(const float *x, const uint4 *Wp, const float *shift, void *y, int N, int Cin, int Cout, int T, int V,
                    int K, int stride, int Tout, const Bf16Plan &pl, bool bf16out, float act_lo, hipStream_t st) {
-    const dim3 grid(ceil_div(Tout * V, NPB), Cout / 128, N);
+    const dim3 grid(ceil_div(Tout * V, NPB), ceil_div(Cout, 128), N);
     if (bf16out) {
         auto kern = tcn_mfma_bf16_kernel<JPR, TERMS, true, KT>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
@@ -616,13 +619,14 @@ bool bf16_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned
 }
 
 bool bf16_packs(int Cin, int Cout, unsigned math) {
-    return (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) && Cin % CCB == 0 && Cout % 128 == 0;
+    return (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) && Cin % CCB == 0 && (Cout % 128 == 0 || Cout == 64);
 }
 
 int launch_tcn_pack_bf16(const float *W, const float *scale, void *Wp, int Cin, int Cout, int K, hipStream_t st) {
-    const size_t total = (size_t)Cin * Cout * K * 2;
+    const int CoutP = (Cout + 127) / 128 * 128;
+    const size_t total = (size_t)Cin * CoutP * K * 2;
     hipLaunchKernelGGL(tcn_pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, scale,
-                       (unsigned short *)Wp, Cin, Cout, K);
+                       (unsigned short *)Wp, Cin, Cout, CoutP, K);
     STGCN_LAUNCH_CHECK("tcn_pack_bf16_kernel");
     return STGCN_OK;
 }

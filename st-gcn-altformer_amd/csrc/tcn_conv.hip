@@ -473,8 +473,9 @@ inline bool mfma_f32_shape_ok(int Cin, int Cout, int V, int K, int stride, int T
 
 // =========================================================================================
 size_t tcn_packed_bytes(int Cin, int Cout, int K, unsigned flags) {
-    (void)flags;  // f32 and VALU layouts are both one float per weight
-    return align_up((size_t)Cin * Cout * K * sizeof(float), 256);
+    // f32 and VALU layouts are one float per weight, the bf16 layout two bf16 images; the latter pads 64 output channels to 128
+    const int CoutP = bf16_packs(Cin, Cout, flags & STGCN_MATH_MASK) ? (Cout + 127) / 128 * 128 : Cout;
+    return align_up((size_t)Cin * CoutP * K * sizeof(float), 256);
 }
 
 // true when launch_tcn_pack lays the weights out in MFMA fragment order for this shape

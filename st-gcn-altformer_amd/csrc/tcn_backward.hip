@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void tcn_wgrad_valu_kernel(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// wgrad on the bf16 matrix cores (stride 1, K <= 9, Cout % 128 == 0, Cin % 32 == 0).
+// wgrad on the bf16 matrix cores (stride 1, K <= 9, Cout % 128 == 0 or Cout == 64, Cin % 32 == 0).
 //
 // GEMM view:  dW[o][(c,k)] = sum_p A[o][p] * B[p][(c,k)],  A = dz,  B[p][(c,k)] = x[c][p + (k-pad)*V]  — the
 // contraction runs over PIXELS, which are contiguous in memory for a fixed channel in both operands, i.e. both are
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(WG_THREADS) void tcn_wgrad_mfma_kernel(const float 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = o0 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                dst[((size_t)o * Cin + c0 + (lane & 31)) * K + k] = acc[kk][r];
+                if (o < Cout) dst[((size_t)o * Cin + c0 + (lane & 31)) * K + k] = acc[kk][r];   // (rows >= Cout: dz read as zeros)
             }
         }
     }
@@ -477,7 +477,7 @@ struct WgradPlan {
 
 inline WgradPlan plan_wgrad(int N, int Cin, int Cout, int T, int V, int K, int stride) {
     WgradPlan pl;
-    if (stride != 1 || K > 2 * KHMAX - 1 || K < 1 || Cout % 128 != 0 || Cin % 32 != 0) return pl;
+    if (stride != 1 || K > 2 * KHMAX - 1 || K < 1 || (Cout % 128 != 0 && Cout != 64) || Cin % 32 != 0) return pl;   // (64: half-empty tile)
     if ((K & 1) == 0) return pl;   // the matrix-core kernel indexes dz and x with one frame count (Tout == T: odd K only)
     if ((size_t)(Cin > Cout ? Cin : Cout) * T * V * 4 >= ((size_t)1 << 31)) return pl;   // per-clip buffer resources
     const int Vp = (V + 7) / 8 * 8;
@@ -496,7 +496,7 @@ inline WgradPlan plan_wgrad(int N, int Cin, int Cout, int T, int V, int K, int s
     pl.lds = (size_t)2 * 128 * pl.pitchA + (size_t)2 * 32 * pl.pitchB;
     if (pl.lds > (size_t)kLdsBytes) return pl;
     const int chunks = (T + TFM - 1) / TFM;
-    const int wgs = (Cin / 32) * (Cout / 128);
+    const int wgs = (Cin / 32) * ceil_div(Cout, 128);
     int splits = 256 / wgs;                       // about one workgroup per CU
     if (splits < 1) splits = 1;
     if (splits > N * chunks) splits = N * chunks;
@@ -586,7 +586,7 @@ int launch_tcn_wgrad(const float *dz, const float *x, float *dW, float *part, in
     const unsigned math = flags & STGCN_MATH_MASK;
     const WgradPlan pl = plan_wgrad(N, Cin, Cout, T, V, K, stride);
     if ((math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) && pl.ok && part != nullptr) {
-        const dim3 grid(Cin / 32, Cout / 128, pl.splits);
+        const dim3 grid(Cin / 32, ceil_div(Cout, 128), pl.splits);
 #define LAUNCH_WGRAD(TERMS, UBN)                                                                                       \
     do {                                                                                                               \
         STGCN_HIP_CHECK(allow_lds((tcn_wgrad_mfma_kernel<TERMS, UBN>), pl.lds));                                       \

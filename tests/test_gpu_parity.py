@@ -668,6 +668,7 @@ def _kink_free_cotangent(y_ref, gen):
     (128, 128, 9, 1, 2, 10, 46, True),     # 46 joints: other frame padding / frames per unit in the wgrad
     (64, 128, 9, 2, 2, 21, 22, True),      # strided: plain fp32 kernels
     (32, 64, 5, 1, 2, 9, 22, False),       # no conv bias, K = 5, 64 output channels
+    (64, 64, 9, 1, 3, 40, 22, True),       # TCN_GCN_unit(64, 64): 64 output channels on the 128-channel matrix-core tiles
     (64, 128, 1, 1, 2, 12, 25, True),      # 1x1 (the residual "down" convs of the deeper layers)
     (128, 128, 4, 1, 2, 11, 22, True),     # EVEN K: the forward drops a frame (Tout = T-1); dgrad must not be the
     (32, 64, 2, 1, 2, 7, 22, True)])       #   flipped-weight forward there, wgrad not the Tout==T kernel

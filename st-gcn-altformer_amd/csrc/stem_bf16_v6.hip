@@ -39,6 +39,13 @@ namespace stgcn {
 
 namespace {
 
+// max(x, 0) as ONE v_max_f32 (fmaxf canonicalises its operand first: a second v_max per element in the producer's slots)
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 using namespace bf16k;
 
 constexpr int NP6 = 256;   // output pixels per tile
@@ -244,9 +251,10 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
         pr.d = f32x4{0.f, 0.f, 0.f, 0.f};
         pr.d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pr.wh), f, pr.d, 0, 0, 0);
         pr.d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pr.wl), f, pr.d, 0, 0, 0);
+        asm volatile("" : "+v"(pr.d));        // the producer's result feeds VALU work: keep it out of the AGPR file
     };
     auto prod_finish = [&](char *buf, const Prod &pr) {
-        const float v0 = fmaxf(pr.d[0], 0.f), v1 = fmaxf(pr.d[1], 0.f), v2 = fmaxf(pr.d[2], 0.f), v3 = fmaxf(pr.d[3], 0.f);
+        const float v0 = relu1(pr.d[0]), v1 = relu1(pr.d[1]), v2 = relu1(pr.d[2]), v3 = relu1(pr.d[3]);
         const unsigned h0 = pack_bf16x2(v0, v1), h1 = pack_bf16x2(v2, v3);
         const int off = lds_off(pr.p, pg >> 1) + (pg & 1) * 8;
         *reinterpret_cast<uint2 *>(buf + off) = make_uint2(h0, h1);
@@ -302,15 +310,17 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
             prod_mfma(pr);
             prod_finish(buf0, pr);
         }
-        unsigned boff[KT6][4];                // LDS offsets of this lane's activation rows: (tap, 16-pixel block)
+        // LDS offsets of this lane's activation rows per tap, for the wave's FIRST 16-pixel block: block nb sits exactly
+        // nb * 16 * PXB bytes further (16 more pixels leave the swizzle bit (row >> 3) & 1 alone), which rides in the
+        // ds_read immediate — 9 offset registers instead of 36 (the kernel is at 256 VGPRs + copies through AGPRs).
+        // Pixels past the clip's last one (last tile only) read rows of the image that exist but hold stale data: their
+        // results are never stored.
+        unsigned boff[KT6];
+        {
+            const int q = g.q0 + wave * 64 + (lane & 15);
+            const int prow = q - g.t_first * V;
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            int q = g.q0 + wave * 64 + nb * 16 + (lane & 15);
-            q = min(q, g.q_last);
-            const int t = q / V, v = q - t * V;
-            const int prow = (t - g.t_first) * V + v;
-#pragma unroll
-            for (int tap = 0; tap < KT6; ++tap) boff[tap][nb] = (unsigned)lds_off(prow + tap * V, chh);
+            for (int tap = 0; tap < KT6; ++tap) boff[tap] = (unsigned)lds_off(prow + tap * V, chh);
         }
         f32x4 acc[8][4];
 #pragma unroll
@@ -328,8 +338,8 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
             constexpr int l0 = decltype(l0_c)::value, l1 = l0 + 1, nb = decltype(nb_c)::value;
             constexpr bool lo_img = decltype(lo_c)::value;
             const char *b0 = (l0 >= KT6 ? buf1 : buf0), *b1 = (l1 >= KT6 ? buf1 : buf0);
-            const unsigned o0 = boff[l0 % KT6][nb], o1 = boff[l1 % KT6][nb];
-            const char *p = (sel ? b1 : b0) + (sel ? o1 : o0) + (lo_img ? img_bytes : 0);
+            const unsigned o0 = boff[l0 % KT6], o1 = boff[l1 % KT6];
+            const char *p = (sel ? b1 : b0) + (sel ? o1 : o0) + (nb * 16 * PXB) + (lo_img ? img_bytes : 0);
             if constexpr (lo_img) b.lo[nb] = rd(p); else b.hi[nb] = rd(p);
         };
         using IC0 = std::integral_constant<int, 0>;
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
                             if constexpr (w == 2) pr.fb = Fs[(size_t)pg * ROWS + pr.p];
                             if constexpr (w == 10) prod_mfma(pr);
                             if constexpr (w == 14) {
-                                pv0 = fmaxf(pr.d[0], 0.f); pv1 = fmaxf(pr.d[1], 0.f); pv2 = fmaxf(pr.d[2], 0.f); pv3 = fmaxf(pr.d[3], 0.f);
+                                pv0 = relu1(pr.d[0]); pv1 = relu1(pr.d[1]); pv2 = relu1(pr.d[2]); pv3 = relu1(pr.d[3]);
                             }
                             if constexpr (w == 15) { ph0 = pack_bf16x2(pv0, pv1); ph1 = pack_bf16x2(pv2, pv3); }
                             if constexpr (w == 16) poff = lds_off(pr.p, pg >> 1) + (pg & 1) * 8;
@@ -428,6 +438,9 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
                     } else {
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h, acc[mb][nb], 0, 0, 0);
                     }
+                    // (the accumulators' home is the AGPR file: without this hint hipcc kept 16 of the 32 blocks in VGPRs and
+                    //  copied each through an AGPR quad around its MFMAs — 64 v_accvgpr_write per period)
+                    if constexpr (term == TERMS - 1) asm volatile("" : "+a"(acc[mb][nb]));
 #ifndef V6_NOFILL   // (diagnostic variant: the MFMA stream alone; results are wrong)
                     static_for6<i * (96 / NM), (i + 1) * (96 / NM)>(filler);
 #endif

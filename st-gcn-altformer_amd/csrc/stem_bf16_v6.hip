@@ -251,7 +251,17 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
         pr.d = f32x4{0.f, 0.f, 0.f, 0.f};
         pr.d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pr.wh), f, pr.d, 0, 0, 0);
         pr.d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pr.wl), f, pr.d, 0, 0, 0);
-        asm volatile("" : "+v"(pr.d));        // the producer's result feeds VALU work: keep it out of the AGPR file
+    };
+    // The same inside the slot-structured loop, with a VGPR destination: the result feeds VALU work, and through the
+    // builtin hipcc computed it in AGPRs and copied it out (4 v_accvgpr_read + an s_nop 6 per block).  As inline asm the
+    // hazard recogniser does not see the matrix-core write: the consumer sits four slots (>= 4 main MFMAs, 64+ cycles)
+    // further down, far beyond the 7 wait states a 4-pass MFMA result needs; the second MFMA accumulates onto the first
+    // with identical vDst / SrcC (back-to-back forwarding).
+    auto prod_mfma_slots = [&](Prod &pr) {
+        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+        const u32x4 wh = __builtin_bit_cast(u32x4, pr.wh), wl = __builtin_bit_cast(u32x4, pr.wl), fb = __builtin_bit_cast(u32x4, pr.fb);
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(pr.d) : "v"(wh), "v"(fb));
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(pr.d) : "v"(wl), "v"(fb));
     };
     auto prod_finish = [&](char *buf, const Prod &pr) {
         const float v0 = relu1(pr.d[0]), v1 = relu1(pr.d[1]), v2 = relu1(pr.d[2]), v3 = relu1(pr.d[3]);
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
                             }
                             if constexpr (w == 1) pr.wl = W12q[(size_t)(2 + (pg & 1)) * C + pch * CCB + pl];
                             if constexpr (w == 2) pr.fb = Fs[(size_t)pg * ROWS + pr.p];
-                            if constexpr (w == 10) prod_mfma(pr);
+                            if constexpr (w == 10) { if constexpr (TERMS == 3) prod_mfma_slots(pr); else prod_mfma(pr); }   // (TERMS == 1 packs three fillers per slot: too close to the consumer for the unchecked form)
                             if constexpr (w == 14) {
                                 pv0 = relu1(pr.d[0]); pv1 = relu1(pr.d[1]); pv2 = relu1(pr.d[2]); pv3 = relu1(pr.d[3]);
                             }

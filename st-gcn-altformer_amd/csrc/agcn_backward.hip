@@ -256,22 +256,22 @@ __global__ __launch_bounds__(256) void agcn_bwd_prep_kernel(const float *__restr
     wda[e] = f < SC ? Wd[((size_t)(f / CIN) * Cout + o) * CIN + (f % CIN)] * bn_w[o] * inv_m[o] : 0.f;
 }
 
-// G partials -> fp64 sums, fixed order: thread (e = tid & 31, grp = tid >> 5) adds partials grp, grp+8, ...; the 8 sub-sums of
+// G partials -> fp64 sums, fixed order: thread (e = tid & 31, grp = tid >> 5) adds partials grp, grp+32, ...; the 32 sub-sums of
 // an element are then added in order.
-__global__ __launch_bounds__(256) void agcn_bwd_gsum_kernel(const float *__restrict__ part_g, int parts, int total,
-                                                            double *__restrict__ G) {
-    __shared__ double sub[8][32];
+__global__ __launch_bounds__(1024) void agcn_bwd_gsum_kernel(const float *__restrict__ part_g, int parts, int total,
+                                                             double *__restrict__ G) {
+    __shared__ double sub[32][32];
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + el;
     double a = 0.0;
     if (e < total)
-        for (int p = grp; p < parts; p += 8) a += (double)part_g[(size_t)p * total + e];
+        for (int p = grp; p < parts; p += 32) a += (double)part_g[(size_t)p * total + e];
     sub[grp][el] = a;
     __syncthreads();
     if (grp != 0 || e >= total) return;
     double s = 0.0;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) s += sub[g][el];
+    for (int g = 0; g < 32; ++g) s += sub[g][el];
     G[e] = s;
 }
 
@@ -763,7 +763,7 @@ int launch_agcn_bwd(const float *x, const float *P, const float *A_eff, const fl
     }
 #undef LAUNCH_GATHER
     STGCN_LAUNCH_CHECK("agcn_bwd_gather_kernel");
-    hipLaunchKernelGGL(agcn_bwd_gsum_kernel, dim3(ceil_div(Cout * NG, 32)), dim3(256), 0, st, part_g, pl.grid, Cout * NG, G);
+    hipLaunchKernelGGL(agcn_bwd_gsum_kernel, dim3(ceil_div(Cout * NG, 32)), dim3(1024), 0, st, part_g, pl.grid, Cout * NG, G);
     STGCN_LAUNCH_CHECK("agcn_bwd_gsum_kernel");
     hipLaunchKernelGGL(agcn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, G, mom, (double)N * T * V, Wd, bd, Wdown, bdown, bn_w,
                        dbn_w, stats, dWd, dbd, dWdown, dbdown, dgamma, dbeta, ddgamma, ddbeta, rr, Cout);

@@ -404,10 +404,11 @@ class unit_agcn(nn.Module):
                 raise NotImplementedError(
                     "unit_agcn: the HIP backward covers V <= 64 joints and coff_embedding >= 4; this call is outside it")
             y = _AgcnTrainFn.apply(self, x, *self._train_params())
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
+            with torch.no_grad():                  # (one launch for both counters)
                 if self._has_down():
-                    self.down[1].num_batches_tracked += 1
+                    torch._foreach_add_([bn.num_batches_tracked, self.down[1].num_batches_tracked], 1)
+                else:
+                    bn.num_batches_tracked += 1
             return y
         down_bn = None
         if self._has_down():

@@ -369,6 +369,21 @@ __global__ __launch_bounds__(256) void agcn_bwd_finalize_kernel(
 //   dM_s[k][l] = sum_{v,w} dS_s[v,w] X2[(k,v),(l,w)]                   (the 4x4 bilinear form of the two embeddings)
 // Work units are dealt round-robin to the 8 waves: u blocks (subset, row block, column block), dP blocks (subset, v block,
 // w block, K part), X2 blocks (I <= J).  MAXU / MAXG: static bounds of the latter two per wave.
+// K loop of one 16 x 16 block: operands of four k-steps are fetched before their four MFMAs (hipcc does not pipeline the
+// plain loop: every step then waits out its own LDS round trips — two dependent ones where a row table is involved).
+template <class FA, class FB>
+__device__ __forceinline__ void mfma_ksteps(f32x4 &acc, int k0, int k1, FA fa, FB fb) {
+    int ks = k0;
+    for (; ks + 4 <= k1; ks += 4) {
+        float a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = fa(ks + q); b[q] = fb(ks + q); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], acc, 0, 0, 0);
+    }
+    for (; ks < k1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa(ks), fb(ks), acc, 0, 0, 0);
+}
+
 constexpr int ROWTAB = 784;   // (k,t) row -> LDS offset k*FP + t*V of the chunk, -1 = no such row
 
 template <int MAXU, int MAXG>
@@ -478,12 +493,9 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_attn_kernel(
                 const int s = uu / (nrb * nvb), rb = (uu / nvb) % nrb, wb = uu % nvb;
                 const int off = rowtab[rb * 16 + l16], w = wb * 16 + l16;
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                for (int ks = 0; ks < ksteps_u; ++ks) {
-                    const int v = 4 * ks + lq;
-                    const float a = (off >= 0 && v < V) ? Xs[off + v] : 0.f;
-                    const float b = (v < V && w < V) ? Ps[(s * V + v) * V + w] : 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-                }
+                mfma_ksteps(acc, 0, ksteps_u,
+                            [&](int ks) { const int v = 4 * ks + lq; return (off >= 0 && v < V) ? Xs[off + v] : 0.f; },
+                            [&](int ks) { const int v = 4 * ks + lq; return (v < V && w < V) ? Ps[(s * V + v) * V + w] : 0.f; });
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int o2 = rowtab[rb * 16 + 4 * lq + i];
@@ -496,13 +508,10 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_attn_kernel(
 #pragma unroll
                 for (int i = 0; i < MAXG; ++i) {
                     if (gI[i] >= 0) {
-                        for (int ks = 0; ks < ksteps_g; ++ks) {
-                            const int t = 4 * ks + lq;
-                            const bool ok = t < tf;
-                            const float a = !ok ? 0.f : (goA[i] >= 0 ? Xs[goA[i] + t * V] : (goA[i] == -1 ? 1.f : 0.f));
-                            const float b = !ok ? 0.f : (goB[i] >= 0 ? Xs[goB[i] + t * V] : (goB[i] == -1 ? 1.f : 0.f));
-                            accG[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, accG[i], 0, 0, 0);
-                        }
+                        const int oa = goA[i], ob_ = goB[i];
+                        mfma_ksteps(accG[i], 0, ksteps_g,
+                                    [&](int ks) { const int t = 4 * ks + lq; return t >= tf ? 0.f : (oa >= 0 ? Xs[oa + t * V] : (oa == -1 ? 1.f : 0.f)); },
+                                    [&](int ks) { const int t = 4 * ks + lq; return t >= tf ? 0.f : (ob_ >= 0 ? Xs[ob_ + t * V] : (ob_ == -1 ? 1.f : 0.f)); });
                     }
                 }
             }
@@ -529,12 +538,9 @@ __global__ __launch_bounds__(NTB) void agcn_bwd_attn_kernel(
                 if (uS[i] >= 0) {
                     const int v = uV[i] * 16 + l16, w = uW[i] * 16 + l16;
                     const float *du = DUs + uS[i] * CIN * FP;
-                    for (int ks = uK0[i]; ks < uK1[i]; ++ks) {
-                        const int off = rowtab[4 * ks + lq];
-                        const float a = (off >= 0 && v < V) ? Xs[off + v] : 0.f;
-                        const float b = (off >= 0 && w < V) ? du[off + w] : 0.f;
-                        accP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, accP[i], 0, 0, 0);
-                    }
+                    mfma_ksteps(accP[i], uK0[i], uK1[i],
+                                [&](int ks) { const int off = rowtab[4 * ks + lq]; return (off >= 0 && v < V) ? Xs[off + v] : 0.f; },
+                                [&](int ks) { const int off = rowtab[4 * ks + lq]; return (off >= 0 && w < V) ? du[off + w] : 0.f; });
                 }
             }
         }

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void agcn_expand_generic_kernel(
 // Epilogue: + folded constants (+ x for the identity residual), ReLU unless raw, 64-byte segments per channel row.
 // v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation (same 1e-4 gate as every fp32 path).
 template <int NOW /* o-blocks per wave */, int NPB /* pixel blocks per wave */>
-__global__ __launch_bounds__(512) void agcn_expand_mfma_kernel(
+__global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kernel(
     const float *__restrict__ x, const float *__restrict__ P, const float *__restrict__ Wd,
     const float *__restrict__ bd, const float *__restrict__ Wdown, const float *__restrict__ bdown,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
@@ -294,12 +294,24 @@ __global__ __launch_bounds__(512) void agcn_expand_mfma_kernel(
 #pragma unroll
         for (int b = 0; b < NPB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // x rows of a chunk: a wave per two channel rows, lanes along the pixels; fetched one chunk ahead into registers
+    float xr_[2][4];
+    auto xfetch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float *xr = xn + (size_t)(c0 + wave + 8 * j) * plane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int p = lane + 64 * q; xr_[j][q] = p < px ? xr[p] : 0.f; }
+        }
+    };
+    xfetch(0);
     for (int c0 = 0; c0 < Cin; c0 += 16) {
         __syncthreads();                                    // previous chunk's rows fully consumed (and Ps loaded)
-        for (int r = wave; r < 16; r += 8) {                // a wave per channel row, lanes along the pixels
-            const float *xr = xn + (size_t)(c0 + r) * plane;
-            for (int p = lane; p < 256; p += 64) Xs[r * PXP + p] = p < px ? xr[p] : 0.f;
-        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Xs[(wave + 8 * j) * PXP + lane + 64 * q] = xr_[j][q];
+        if (c0 + 16 < Cin) xfetch(c0 + 16);
         __syncthreads();
         // ---- aggregation blocks (s, t, w block): rows = the 16 channels
         for (int u = wave; u < 3 * tf * nvb; u += 8) {
@@ -308,7 +320,20 @@ __global__ __launch_bounds__(512) void agcn_expand_mfma_kernel(
             f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
             const float *xr = Xs + l16 * PXP + t * V;
             const float *pr = Ps + s * VV + (w < V ? w : 0);
-            for (int ks = 0; ks < (V + 3) / 4; ++ks) {
+            const int nks = (V + 3) / 4;
+            int ks = 0;
+            for (; ks + 4 <= nks; ks += 4) {                // operands of four k-steps ahead of their MFMAs (LDS round trips)
+                float av[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int v = 4 * (ks + q) + lq;
+                    av[q] = v < V ? xr[v] : 0.f;
+                    bv[q] = (v < V && w < V) ? pr[v * V] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], a4, 0, 0, 0);
+            }
+            for (; ks < nks; ++ks) {
                 const int v = 4 * ks + lq;
                 const float av = v < V ? xr[v] : 0.f;
                 const float bv = (v < V && w < V) ? pr[v * V] : 0.f;
@@ -338,14 +363,19 @@ __global__ __launch_bounds__(512) void agcn_expand_mfma_kernel(
             const int pb = pb0 + b * wpo;
             if (pb * 16 < px) {
                 const float *br = Ub + lq * PXP + pb * 16 + l16;
-                float bf[16];
 #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) bf[ks] = (4 * ks < KK) ? br[(size_t)4 * ks * PXP] : 0.f;
+                for (int kh = 0; kh < 2; ++kh) {            // eight k-steps' operands at a time (register budget: 128)
+                    float bf[8];
 #pragma unroll
-                for (int a = 0; a < NOW; ++a)
+                    for (int k8 = 0; k8 < 8; ++k8) { const int ks = kh * 8 + k8; bf[k8] = (4 * ks < KK) ? br[(size_t)4 * ks * PXP] : 0.f; }
 #pragma unroll
-                    for (int ks = 0; ks < 16; ++ks)
-                        if (4 * ks < KK) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[a][ks], bf[ks], acc[a][b], 0, 0, 0);
+                    for (int a = 0; a < NOW; ++a)
+#pragma unroll
+                        for (int k8 = 0; k8 < 8; ++k8) {
+                            const int ks = kh * 8 + k8;
+                            if (4 * ks < KK) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[a][ks], bf[k8], acc[a][b], 0, 0, 0);
+                        }
+                }
             }
         }
     }

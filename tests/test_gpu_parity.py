@@ -1147,3 +1147,47 @@ def test_fused_stem_256_channels(V, T, N, dev):
         fused = tcn(gcn(x.to(dev)))
     parity_gate(two, ref, 1e-4, "two-stage, 256 channels")
     parity_gate(fused, ref, 1e-4, "fused, 256 channels")
+
+
+@pytest.mark.parametrize("N,T,V,cout", [
+    (64, 180, 22, 128),     # the stem's own size class: 18 frame chunks of 10 frames, 16-byte loads
+    (8, 200, 46, 128),      # two-hand graph: 4-frame chunks, 3 x 3 blocks in the attention part
+    (6, 500, 22, 64),       # BASELINE configs[2] frame count, 64 output channels
+    (5, 63, 25, 128),       # odd T*V: the scalar-load path of the gather kernel
+    (3, 37, 22, 256)])      # 256 output channels (8 channel blocks per chunk)
+def test_stem_backward_moment_form_matches_gemm_chain_at_size(N, T, V, cout, dev):
+    """The two HIP implementations of the stem-class graph-conv backward against each other at sizes the fp64 oracle does
+    not reach in seconds: the moment form (one pass over dy / y, everything else from the forward's feature moments) and
+    the generic chain of batched fp32 GEMMs (which rebuilds both branches and takes the BatchNorm statistics from them).
+    Each is pinned to the oracle at small sizes; here they must agree on every gradient to 2e-4 of its tensor's max."""
+    from stgcn_amd import functional as F
+    gcn, _, _, _, gen = _random_stem(V, None, 5000 + T + V + cout, dev, c=cout)
+    gcn.train()
+    x = torch.randn(N, 3, T, V, generator=gen).to(dev)
+    st = gcn._staged(dev)
+    bn, d = gcn.bn, gcn.down[1]
+    y, P, zm, zd, stats = F.agcn_forward_train(
+        x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"], st["bdown"],
+        (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var),
+        (d.weight.detach(), d.bias.detach(), d.running_mean, d.running_var), 0.1, 1e-5, save=True)
+    assert zm is None and zd is None                       # the moments path: no branch was kept
+    # cotangent zero next to the ReLU kink (cf. _kink_free_cotangent): the moment form takes the mask from the forward's own
+    # y, the chain from branches it rebuilds — an element whose pre-activation is within rounding of zero may differ, and a
+    # flipped mask bit moves a gradient by a finite amount
+    dy = torch.randn(y.shape, generator=gen).to(dev) * (y > 2e-2 * y.abs().max()).float()
+    args = (x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"], st["bdown"], P, None, None,
+            bn.weight.detach(), bn.bias.detach(), d.weight.detach(), d.bias.detach(), stats, dy)
+    fused = F.agcn_backward_train(*args, y=y)              # moment form
+    chain = F.agcn_backward_train(*args, y=None)           # GEMM chain (rebuilds zm / zd in its workspace)
+    torch.cuda.synchronize()
+    bad = []
+    for k in sorted(chain):
+        a, b = fused[k].double(), chain[k].double()
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), k
+        scale = b.abs().max().item()
+        if k in ("dbd", "dbdown", "dba"):                  # analytically zero (see _compare_grads): rounding noise both ways
+            scale = max(scale, chain["dWd" if k == "dbd" else ("dWdown" if k == "dbdown" else "dWa")].abs().max().item())
+        err = (a - b).abs().max().item()
+        if err > 2e-4 * max(scale, 1e-30):
+            bad.append(f"{k}: {err:.3e} vs 2e-4*{scale:.3e}")
+    assert not bad, "; ".join(bad)

@@ -104,7 +104,8 @@ int launch_agcn_expand(const float *x, const float *P, const float *Wd, const fl
                        float *y, int N, int Cin, int Cout, int T, int V, int S, int mode, hipStream_t st);
 
 // temporal conv
-size_t tcn_packed_bytes(int Cin, int Cout, int K, unsigned flags);
+size_t tcn_packed_bytes(int Cin, int Cout, int K, unsigned flags);          // everything launch_tcn_pack writes
+size_t tcn_packed_single_bytes(int Cin, int Cout, int K, unsigned flags);   // the first layout alone (a pair-order copy may follow)
 int launch_tcn_pack(const float *W, const float *scale, void *Wp, int Cin, int Cout, int K,
                     unsigned flags, hipStream_t st);
 int launch_tcn(const float *x, const void *Wp, const float *shift, void *y, int N, int Cin,
@@ -140,6 +141,12 @@ int launch_stem_v6(const float *x, bool x_ntvc, const void *pfrag, const void *p
 
 // stand-alone temporal conv in the large-tile persistent form (stem_bf16_v4.hip): K = 9, stride 1, Cout % 128 == 0
 bool tcn_v4_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
+// ... and in KF6's form (tcn_bf16_v6.hip): one wave per SIMD, pair-order weights (appended to the packed blob by launch_tcn_pack)
+bool tcn_v6_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
+bool tcn_v6_packs(int Cin, int Cout, int K, unsigned math);
+int launch_tcn_pack_pairs_padded(const float *W, const float *scale, void *Wq, int Cin, int Cout, hipStream_t st);
+int launch_tcn_v6(const float *x, const void *Wq, const float *shift, void *y, int N, int Cin, int Cout, int T, int V, int K,
+                  int stride, unsigned flags, hipStream_t st);
 int launch_tcn_v4(const float *x, const void *Wp, const float *shift, void *y, int N, int Cin, int Cout, int T, int V, int K,
                   int stride, unsigned flags, hipStream_t st);
 

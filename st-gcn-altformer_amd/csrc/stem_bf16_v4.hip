@@ -926,7 +926,7 @@ int launch_stem_v4(const float *x, bool x_ntvc, const float *feat, const void *p
     // the 256-pixel tile runs with one wave per SIMD (KF6, stem_bf16_v6.hip) where that form covers the shape
     // (diagnostic builds: mask bit 256 keeps the eight-wave form for A/B runs in one process)
     if (pl.nj == 2 && stem_v6_supported(C, T, V, K, flags) && !(ablate_mask() & 256))
-        return launch_stem_v6(x, x_ntvc, feat, prep_w12, (const char *)Wp + tcn_packed_bytes(C, C, K, flags), shift, out, N, C, T,
+        return launch_stem_v6(x, x_ntvc, feat, prep_w12, (const char *)Wp + tcn_packed_single_bytes(C, C, K, flags), shift, out, N, C, T,
                               V, K, flags, st);
     const float4 *f4 = (const float4 *)feat;
     const float *W12 = (const float *)prep_w12;

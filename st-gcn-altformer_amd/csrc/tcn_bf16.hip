@@ -613,7 +613,7 @@ bool bf16_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned
         StemPlan sp;
         return Cin == Cout && stride == 1 && plan_stem_bf16(Cin, V, K, T, terms, sp);
     }
-    if (tcn_v4_supported(Cin, Cout, T, V, K, stride, flags)) return true;
+    if (tcn_v6_supported(Cin, Cout, T, V, K, stride, flags) || tcn_v4_supported(Cin, Cout, T, V, K, stride, flags)) return true;
     Bf16Plan pl;
     return plan_bf16(Cin, Cout, V, K, stride, Tout, terms, pl);
 }
@@ -646,7 +646,12 @@ int launch_tcn_bf16(const float *x, const float *P, const float *W12, const void
         if (terms == 3) return dispatch_stem<3>(x, P, W12, (const uint4 *)Wp, shift, y, N, Cin, T, V, K, sp, bf16out, opt, st);
         return dispatch_stem<1>(x, P, W12, (const uint4 *)Wp, shift, y, N, Cin, T, V, K, sp, bf16out, opt, st);
     }
-    if (tcn_v4_supported(Cin, Cout, T, V, K, stride, flags))   // K = 9, stride 1: large-tile persistent kernel
+    // K = 9, stride 1: large-tile persistent kernels — one wave per SIMD on 16x16x32 where that form covers the shape
+    // (diagnostic builds: mask 8192 keeps the eight-wave kernel for A/B runs in one process)
+    if (tcn_v6_supported(Cin, Cout, T, V, K, stride, flags) && !(ablate_mask() & 8192))
+        return launch_tcn_v6(x, (const char *)Wp + tcn_packed_single_bytes(Cin, Cout, K, flags), shift, y, N, Cin, Cout, T, V, K,
+                             stride, flags, st);
+    if (tcn_v4_supported(Cin, Cout, T, V, K, stride, flags))
         return launch_tcn_v4(x, Wp, shift, y, N, Cin, Cout, T, V, K, stride, flags, st);
     Bf16Plan pl;
     if (Tout < 1 || !plan_bf16(Cin, Cout, V, K, stride, Tout, terms, pl))

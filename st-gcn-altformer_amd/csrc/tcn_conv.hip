@@ -472,10 +472,16 @@ inline bool mfma_f32_shape_ok(int Cin, int Cout, int V, int K, int stride, int T
 }  // namespace
 
 // =========================================================================================
-size_t tcn_packed_bytes(int Cin, int Cout, int K, unsigned flags) {
+size_t tcn_packed_single_bytes(int Cin, int Cout, int K, unsigned flags) {
     // f32 and VALU layouts are one float per weight, the bf16 layout two bf16 images; the latter pads 64 output channels to 128
     const int CoutP = bf16_packs(Cin, Cout, flags & STGCN_MATH_MASK) ? (Cout + 127) / 128 * 128 : Cout;
     return align_up((size_t)Cin * CoutP * K * sizeof(float), 256);
+}
+
+// bf16 modes, K = 9: a second copy in pair order (K3v6, tcn_bf16_v6.hip) follows the first
+size_t tcn_packed_bytes(int Cin, int Cout, int K, unsigned flags) {
+    const size_t one = tcn_packed_single_bytes(Cin, Cout, K, flags);
+    return tcn_v6_packs(Cin, Cout, K, flags & STGCN_MATH_MASK) ? 2 * one : one;
 }
 
 // true when launch_tcn_pack lays the weights out in MFMA fragment order for this shape
@@ -488,7 +494,11 @@ int launch_tcn_pack(const float *W, const float *scale, void *Wp, int Cin, int C
     const unsigned math = flags & STGCN_MATH_MASK;
     const size_t total = (size_t)Cin * Cout * K;
     const int blocks = (int)((total + 255) / 256);
-    if (bf16_packs(Cin, Cout, math)) return launch_tcn_pack_bf16(W, scale, Wp, Cin, Cout, K, st);
+    if (bf16_packs(Cin, Cout, math)) {
+        const int rc = launch_tcn_pack_bf16(W, scale, Wp, Cin, Cout, K, st);
+        if (rc != STGCN_OK || !tcn_v6_packs(Cin, Cout, K, math)) return rc;
+        return launch_tcn_pack_pairs_padded(W, scale, (char *)Wp + tcn_packed_single_bytes(Cin, Cout, K, flags), Cin, Cout, st);
+    }
     if (packs_as_mfma(Cin, Cout, math)) {
         hipLaunchKernelGGL(tcn_pack_f32_kernel, dim3(blocks), dim3(256), 0, st, W, scale, (float *)Wp, Cin,
                            Cout, K);
@@ -569,7 +579,7 @@ static bool stem_prep_has_pairs(int C, int K, unsigned flags) {
 
 size_t stem_prep_bytes(int Cin, int C, int K, int S, unsigned flags) {
     (void)Cin; (void)S;
-    return stem_w12_bytes(C) + tcn_packed_bytes(C, C, K, flags) * (stem_prep_has_pairs(C, K, flags) ? 2 : 1);
+    return stem_w12_bytes(C) + tcn_packed_single_bytes(C, C, K, flags) * (stem_prep_has_pairs(C, K, flags) ? 2 : 1);
 }
 
 static bool stem_shape_ok(int Cin, int C, int V, int K, int S, int T) {
@@ -603,7 +613,7 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
     STGCN_LAUNCH_CHECK("stem_fold_kernel");
     int rc = launch_tcn_pack(Wt, t_scale, (char *)prep + stem_w12_bytes(C), C, C, K, flags, st);
     if (rc != STGCN_OK || !stem_prep_has_pairs(C, K, flags)) return rc;
-    return launch_tcn_pack_bf16_pairs(Wt, t_scale, (char *)prep + stem_w12_bytes(C) + tcn_packed_bytes(C, C, K, flags), C, C, st);
+    return launch_tcn_pack_bf16_pairs(Wt, t_scale, (char *)prep + stem_w12_bytes(C) + tcn_packed_single_bytes(C, C, K, flags), C, C, st);
 }
 
 // workspace of the fused stem: [ P : N*S*V*V floats, 256-B aligned ] then ONE of

@@ -104,41 +104,58 @@ __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restric
 
     // ---- input staging: this lane's four (pixel row, channel half) units of a chunk image -----------------------------
     // (a lane whose unit index runs past the image repeats the last unit: same address, same data, no branch)
-    int up[4], uh[4], uoff[4];               // pixel row, channel half, LDS offset
+    int up[4], uoff[4];                      // pixel row, LDS offset
+    unsigned ugo[4];                         // byte offset of (channel half, pixel row) in the chunk's 16 channel planes
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int u = min(tid + i * NT6, 2 * ROWS - 1);
-        uh[i] = u >= ROWS ? 1 : 0;
-        up[i] = u - uh[i] * ROWS;
-        uoff[i] = lds_off(up[i], uh[i]);
+        const int hh = u >= ROWS ? 1 : 0;
+        up[i] = u - hh * ROWS;
+        uoff[i] = lds_off(up[i], hh);
+        ugo[i] = (unsigned)((hh * 8 * TV + up[i]) * 4);
     }
-    float pv[4][8];
-    // the element (tile, chunk) the registers hold / are being filled with; geometry of its tile
-    int e_tile = blockIdx.x, e_ch = 0, e_origin = 0, e_span = 0, e_n = 0;
-    auto e_geom = [&]() {
-        const int tl = min(e_tile, ntiles - 1);
-        e_n = tl / tiles_per_clip;
-        const TileGeomB g = tile_geom_b(tl - e_n * tiles_per_clip, V, KT6, 1, T, NP6);
-        e_origin = g.origin;
-        e_span = e_tile < ntiles ? g.span : 0;        // past the last tile: every unit reads as zeros
-    };
-    auto e_advance = [&]() {                 // next element of the sequence
-        if (++e_ch == nch) { e_ch = 0; e_tile += gridDim.x; }
-        e_geom();
-    };
-    // 8 dword loads of unit i of the current element (lanes run along the pixels of one channel; the 8 channel strides ride
-    // in the scalar offset; a pixel outside the clip gets an offset past num_records, which reads as zero)
-    auto load_unit = [&](int i) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(x + ((size_t)e_n * Cin + e_ch * CCB) * TV), 0, (unsigned)(CCB * TV * 4), 0x00020000);
-        const int gi = e_origin + up[i];
-        const bool ok = up[i] < e_span && gi >= 0 && gi < TV;
-        const unsigned off = ok ? (unsigned)((uh[i] * 8 * TV + gi) * 4) : 0x7ffffff0u;
+    int so[8];                               // scalar offsets of a unit's 8 channel planes
 #pragma unroll
-        for (int c = 0; c < 8; ++c) pv[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, c * TV * 4, 0));
+    for (int c = 0; c < 8; ++c) so[c] = __builtin_amdgcn_readfirstlane(c * TV * 4);
+    float pv[4][8];
+    // The element (tile, chunk) the registers hold / are being filled with belongs to the current tile or (from the last
+    // period's window A on) to the workgroup's next one.  Per tile, all scalar: the byte offset of the tile's first pixel row,
+    // the range [lo, lo + w) of pixel rows that lie inside the clip, and the address of the clip's channel plane 0.
+    struct EGeom { int o4, lo; unsigned w; const float *base; };
+    auto geom_of = [&](int t) {
+        const int tl = min(t, ntiles - 1);
+        const int en = tl / tiles_per_clip;
+        const TileGeomB g = tile_geom_b(tl - en * tiles_per_clip, V, KT6, 1, T, NP6);
+        const int lo = max(0, -g.origin), hi = min(t < ntiles ? g.span : 0, TV - g.origin);   // past the last tile: empty
+        return EGeom{g.origin * 4, lo, (unsigned)max(hi - lo, 0), x + (size_t)en * Cin * TV};
     };
-    auto load_unit_one = [&](int i, int c, unsigned off, const __amdgpu_buffer_rsrc_t &rs) {
-        pv[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, c * TV * 4, 0));
+    EGeom gcur = geom_of(blockIdx.x), gnxt = geom_of(blockIdx.x + gridDim.x);
+    int e_ch = 0, e_o4 = gcur.o4, e_lo = gcur.lo;
+    unsigned e_w = gcur.w;
+    bool e_next = false;
+    __amdgpu_buffer_rsrc_t e_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gcur.base), 0, (unsigned)(CCB * TV * 4), 0x00020000);
+    auto e_advance = [&]() {                 // next element of the sequence (branch-free: it sits in an MFMA slot)
+        const bool wrap = e_ch + 1 == nch;
+        e_ch = wrap ? 0 : e_ch + 1;
+        e_next = e_next || wrap;
+        e_o4 = e_next ? gnxt.o4 : gcur.o4;
+        e_lo = e_next ? gnxt.lo : gcur.lo;
+        e_w = e_next ? gnxt.w : gcur.w;
+        const float *b = (e_next ? gnxt.base : gcur.base) + (size_t)e_ch * CCB * TV;
+        e_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b), 0, (unsigned)(CCB * TV * 4), 0x00020000);
+    };
+    // 8 dword loads of a unit of the current element (lanes run along the pixels of one channel; the 8 channel strides ride
+    // in the scalar offset; a pixel outside the clip gets an offset past num_records, which reads as zero)
+    auto unit_off = [&](int i) -> unsigned {
+        return (unsigned)(up[i] - e_lo) < e_w ? ugo[i] + (unsigned)e_o4 : 0x7ffffff0u;
+    };
+    auto load_unit_one = [&](int i, int c, unsigned off) {
+        pv[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(e_rs, off, so[c], 0));
+    };
+    auto load_unit = [&](int i) {
+        const unsigned off = unit_off(i);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) load_unit_one(i, c, off);
     };
     auto store_unit = [&](char *buf, int i) {
         uint4 hi, lo;
@@ -148,7 +165,6 @@ __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restric
     };
 
     // ---- one-time setup: element 0 -> buf0, element 1 -> registers, weight pairs 0 and 1 ---------------------------------
-    e_geom();
 #pragma unroll
     for (int i = 0; i < 4; ++i) load_unit(i);
 #pragma unroll
@@ -218,7 +234,6 @@ __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restric
                 if constexpr (TERMS == 3) al[0] = al0n;
                 // staging state of the unit in flight through this pair's fillers
                 unsigned sh0 = 0, sh1 = 0, sh2 = 0, sh3 = 0, sl0 = 0, sl1 = 0, sl2 = 0, sl3 = 0, goff = 0;
-                __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, 0, 0x00020000);
                 constexpr int NM = 32 * TERMS;                // MFMAs of the pair
                 auto filler = [&](auto v_c) {
                     constexpr int v = decltype(v_c)::value;
@@ -246,14 +261,8 @@ __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restric
                         if constexpr (TERMS == 3 && w == 6) sl2 = pack_bf16x2(pv[ui][4] - bf16_lo_to_f32(sh2), pv[ui][5] - bf16_hi_to_f32(sh2));
                         if constexpr (TERMS == 3 && w == 7) sl3 = pack_bf16x2(pv[ui][6] - bf16_lo_to_f32(sh3), pv[ui][7] - bf16_hi_to_f32(sh3));
                         if constexpr (TERMS == 3 && w == 8) *reinterpret_cast<uint4 *>(pbuf + img_bytes + uoff[ui]) = make_uint4(sl0, sl1, sl2, sl3);
-                        if constexpr (w == 9) {
-                            grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + ((size_t)e_n * Cin + e_ch * CCB) * TV), 0,
-                                                                    (unsigned)(CCB * TV * 4), 0x00020000);
-                            const int gi = e_origin + up[ui];
-                            const bool ok = up[ui] < e_span && gi >= 0 && gi < TV;
-                            goff = ok ? (unsigned)((uh[ui] * 8 * TV + gi) * 4) : 0x7ffffff0u;
-                        }
-                        if constexpr (w >= 10 && w < 18) load_unit_one(ui, w - 10, goff, grs);
+                        if constexpr (w == 9) goff = unit_off(ui);
+                        if constexpr (w >= 10 && w < 18) load_unit_one(ui, w - 10, goff);
                     }
                     // weights of pair gq + 2 -> the slot pair gq - 1 occupied (its readers passed the last barrier)
                     if constexpr (v >= 4 && v < 8) dma_frag(q2, slot2, v - 4);
@@ -357,6 +366,10 @@ __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restric
                 }
             }
         }
+        // the held element (next tile, chunk 1) becomes "current tile"
+        gcur = gnxt;
+        gnxt = geom_of(tile + 2 * gridDim.x);
+        e_next = false;
     }
     vm_wait_keep<0>();                        // nothing of this workgroup stays in flight behind its end
 }

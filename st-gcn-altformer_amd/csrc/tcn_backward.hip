@@ -402,6 +402,7 @@ __global__ __launch_bounds__(WG_THREADS) void tcn_wgrad_mfma_kernel(const float 
     const char *brow = Bhi + (lane & 31) * pitchB + h * 16 + k_lo * Vp * 2;
     const int aoff_lo = 128 * pitchA, boff_lo = 32 * pitchB;
     const int tapb = Vp * 2;                      // bytes between consecutive taps of a B fragment
+    const int ntap2 = (tg == 0 ? KH : K - KH) - 3;    // taps of this wave's group beyond the first three (K = 9: 2 and 1)
 
     int u = zi;
     if (u < nunits) fetch(u);
@@ -439,7 +440,9 @@ __global__ __launch_bounds__(WG_THREADS) void tcn_wgrad_mfma_kernel(const float 
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
             WGRAD_GROUP(0, 3)
-            WGRAD_GROUP(3, 2)
+            // (the second tap group of K = 9 has four taps, not five: its fifth was computed for nothing — 10 % of the MFMAs)
+            if (ntap2 >= 2) WGRAD_GROUP(3, 2)
+            else if (ntap2 == 1) WGRAD_GROUP(3, 1)
 #undef WGRAD_GROUP
         }
     }

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "st-gcn-altformer_amd")); sys.path.insert(
 import torch
 from stgcn_amd import functional as F
 ap = argparse.ArgumentParser(); ap.add_argument("--env", default="STGCN_ABLATE"); ap.add_argument("--clips", type=int, default=256)
-ap.add_argument("--need-dx", type=int, default=0)
+ap.add_argument("--need-dx", type=int, default=0); ap.add_argument("--val", default="1")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -21,8 +21,8 @@ run = lambda: F.tcn_backward_train(x, W, z, bn[0], bn[1], mean, inv, dy, math=F.
 for _ in range(3): run()
 res = {0: [], 1: []}
 for _ in range(4):
-    for on in (0, 1):
-        if on: os.environ[a.env] = "1"
+    for on in (0, 1):  # 1 -> STGCN_ABLATE set to --val
+        if on: os.environ[a.env] = a.val
         else: os.environ.pop(a.env, None)
         run(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -283,7 +283,7 @@ def main():
     def kernel_name(math):
         from stgcn_amd import _capi
         if args.no_fuse:
-            return "tcn_bf16_v4_kernel" if math in ("bf16x3", "bf16") else "tcn_mfma_f32_kernel"
+            return "tcn_bf16_v6_kernel" if math in ("bf16x3", "bf16") else "tcn_mfma_f32_kernel"
         fl = F._flags({"f32": F.MATH_F32, "bf16x3": F.MATH_BF16X3, "bf16": F.MATH_BF16, "f32_valu": F.MATH_F32_VALU}[math], False)
         return _capi.lib().stgcn_stem_kernel_name(3, 128, T, V, 9, 3, fl).decode() or "?"
 

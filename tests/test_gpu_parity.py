@@ -184,7 +184,8 @@ def test_stem_vs_oracle_ragged(N, T, V, fused, math, dev):
     (128, 128, 9, 1, 41, 22), (64, 128, 9, 2, 40, 22), (128, 256, 9, 2, 33, 22), (256, 256, 9, 1, 12, 46),
     (16, 128, 3, 1, 7, 22), (48, 96, 9, 1, 20, 22), (128, 128, 1, 1, 30, 22), (64, 64, 9, 1, 25, 22),
     (128, 128, 4, 1, 19, 22), (64, 128, 6, 2, 20, 22),       # even K: Tout = (T + 2*((K-1)//2) - K)//stride + 1
-    (64, 64, 9, 1, 180, 22), (32, 64, 9, 2, 31, 25), (64, 64, 1, 1, 9, 46), (128, 64, 3, 1, 14, 22)])   # 64 output channels:
+    (64, 64, 9, 1, 180, 22), (32, 64, 9, 2, 31, 25), (64, 64, 1, 1, 9, 46), (128, 64, 3, 1, 14, 22),    # 64 output channels:
+    (32, 128, 9, 1, 23, 22), (32, 64, 9, 1, 40, 25), (256, 128, 9, 1, 17, 22)])   # K3v6 with one period per tile / eight
     # packed as 128 rows for the bf16 matrix-core kernels (tcn_bf16.hip), rows >= 64 never stored
 @pytest.mark.parametrize("math", ["f32", "bf16x3"])
 def test_tcn_vs_oracle_shapes(cin, cout, K, stride, T, V, math, dev):
@@ -987,7 +988,9 @@ def test_strided_unit2d_backward_vs_reference_gradients(math, dev):
     (16, 128, 30, 200, 7, False),      # one channel chunk, narrow frames: many tiles per clip
     (128, 128, 2, 1, 22, False),       # T = 1
     (64, 64, 20, 180, 22, False),      # TCN_GCN_unit(64, 64): 64 output channels on the 128-channel tile (padded packing)
-    (64, 64, 5, 33, 25, True)])        # ... bf16 output, odd T*V
+    (64, 64, 5, 33, 25, True),         # ... bf16 output, odd T*V
+    (32, 128, 9, 61, 25, False),       # K3v6 with a single period per tile (two channel chunks), many tiles, odd T*V
+    (256, 256, 3, 45, 22, False)])     # eight periods per tile, two output groups
 def test_large_tile_temporal_conv_kernel(cin, cout, N, T, V, out_bf16, dev):
     """K3v4 (stand-alone temporal conv, K = 9, stride 1, bf16x3) against the fp32 VALU kernel on the whole batch and
     against the fp64 oracle on sampled clips; also in raw (pre-activation) mode, which the training forward uses."""

@@ -4,8 +4,10 @@
     STGCN_LIB=st-gcn-altformer_amd/stgcn_amd/libstgcn_hip_abl.so python tools/ablate.py [--clips 256]
 
 For every arithmetic mode and every STGCN_ABLATE mask it times the fused kernel alone (HIP events on the
-launching stream, interleaved rounds in one process).  Masks: 1 producer, 2 MFMAs, 4 epilogue stores,
-8 B-operand LDS reads (bf16 kernels), 16 weight loads (bf16 kernels).  Outputs are wrong when a mask is set.
+launching stream, interleaved rounds in one process).  Masks of the eight-wave kernels (KF4, f32): 1 producer, 2 MFMAs,
+4 epilogue stores, 8 B-operand LDS reads, 16 weight loads — outputs are wrong when one of these is set.  Kernel
+selection masks (results stay correct): 256 = KF4 instead of KF6 (the same-process yardstick of DESIGN.md section 3),
+8192 = K3v4 instead of K3v6 (tools/time_tcn.py), 2048 / 4096 = the plain-FMA generic adjacency / expansion kernels.
 """
 import argparse
 import os

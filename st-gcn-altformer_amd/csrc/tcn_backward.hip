@@ -11,6 +11,8 @@
 // two BatchNorms under one ReLU), the weight flip that turns dgrad (stride 1) into a forward temporal conv run by the
 // existing matrix-core kernels, the matrix-core wgrad (bf16x3, same arithmetic contract as the forward), and plain
 // VALU dgrad / wgrad kernels for every other shape (and as the fp32 cross-check).
+#include <algorithm>
+
 #include "bf16_common.h"
 
 namespace stgcn {
@@ -597,7 +599,9 @@ size_t tcn_wgrad_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int str
     const unsigned math = flags & STGCN_MATH_MASK;
     if (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) {
         const WgradPlan pl = plan_wgrad(N, Cin, Cout, T, V, K, stride);
-        if (pl.ok) return (size_t)pl.splits * Cout * Cin * K * sizeof(float);
+        size_t splits = pl.ok ? (size_t)pl.splits : 0;
+        if (tcn_wgrad_v6_supported(N, Cin, Cout, T, V, K, stride)) splits = std::max(splits, (size_t)tcn_wgrad_v6_splits(N, Cin, Cout));
+        if (splits) return splits * Cout * Cin * K * sizeof(float);
     }
     return 0;
 }
@@ -607,6 +611,17 @@ int launch_tcn_wgrad(const float *dz, const float *x, float *dW, float *part, in
                      int stride, int Tout, unsigned flags, hipStream_t st) {
     const unsigned math = flags & STGCN_MATH_MASK;
     const WgradPlan pl = plan_wgrad(N, Cin, Cout, T, V, K, stride);
+    // one wave per SIMD, ring input tile (tcn_wgrad_v6.hip) where it covers the shape  (diagnostic builds: STGCN_ABLATE=2 off)
+    if ((math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) && part != nullptr && tcn_wgrad_v6_supported(N, Cin, Cout, T, V, K, stride) &&
+        !(ablate_mask() & 2)) {
+        const int rc = launch_tcn_wgrad_v6(dz, x, part, N, Cin, Cout, T, V, K, flags, st);
+        if (rc != STGCN_OK) return rc;
+        const size_t n = (size_t)Cout * Cin * K;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, dW,
+                           tcn_wgrad_v6_splits(N, Cin, Cout), n);
+        STGCN_LAUNCH_CHECK("sum_partials_kernel");
+        return STGCN_OK;
+    }
     if ((math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) && pl.ok && part != nullptr) {
         const dim3 grid(Cin / 32, ceil_div(Cout, 128), pl.splits);
 #define LAUNCH_WGRAD(TERMS, UBN)                                                                                       \

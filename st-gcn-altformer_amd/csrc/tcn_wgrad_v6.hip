@@ -1,0 +1,291 @@
+// Weight gradient of the temporal conv in the one-wave-per-SIMD form (cf. tcn_bf16_v6.hip), for 17 <= V <= 24, stride 1,
+// odd K <= 9, Cin % 32 == 0, Cout % 128 == 0 or 64.
+//
+//   dW[o][c][k] = sum_p dz[o][p] * x[c][p + (k - pad) * V]        (GEMM over PIXELS, see tcn_backward.hip)
+//
+// The eight-wave kernel (tcn_wgrad_mfma_kernel) stages a unit with all waves, then multiplies with all waves; priced in a
+// diagnostic build, of 1.3 ms only 0.26 were MFMAs — the rest vector-memory issue, conversion, barriers and skeleton
+// (DESIGN.md section 7).  Here:
+//   * 256 threads, one wave per SIMD; wave w owns dz channel block w (32 channels) x 32 input channels x ALL taps:
+//     9 accumulators of 32x32 (144 registers, pinned to the AGPR file); no tap groups, no wasted tenth tap;
+//   * a workgroup walks whole CLIPS in units of TWO output frames (3 k-steps of 16 padded pixels, 81 MFMAs per wave);
+//   * the input tile is a RING of 16 frame slots per channel row: a unit adds its two new frames (the other eight of its
+//     ten-frame window are already there); four MFMA-free lead-in units per clip fill the ring;
+//   * two dz tiles; staging of unit g+1 (convert + LDS stores) and the loads of unit g+2 sit BETWEEN the MFMA groups of
+//     unit g — there is no staging phase; one barrier per unit;
+//   * fragment reads of the next tap group are issued before the current group's MFMAs.
+// Partial sums per workgroup, summed in a fixed order by sum_partials_kernel as before.
+#include <type_traits>
+
+#include "bf16_common.h"
+
+namespace stgcn {
+
+namespace {
+
+using namespace bf16k;
+
+constexpr int WQ_THREADS = 256;
+constexpr int WQ_TFM = 2;        // output frames per unit
+constexpr int WQ_UPF = 3;        // 8-pixel pieces per (padded) frame: Vp = 24
+constexpr int WQ_VP = 24;
+constexpr int WQ_RING = 16;      // frame slots of the input ring
+constexpr int WQ_WIN = WQ_TFM + 8;   // window frames of a unit (taps 0 .. 8)
+constexpr int WQ_LEAD = 4;       // lead-in units per clip: (WQ_WIN - WQ_TFM) / WQ_TFM
+constexpr int WQ_PITCH_A = 112;  // bytes per dz row of a unit: 2 frames x 48 B, 16 B x odd
+constexpr int WQ_PITCH_B = 784;  // bytes per input row: 16 slots x 48 B, 16 B x odd
+constexpr int WQ_FRB = 48;       // bytes per frame slot
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_forq(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_forq<I + 1, N>(f);
+    }
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *__restrict__ dz, const float *__restrict__ x,
+                                                                   float *__restrict__ part, int N, int Cin, int Cout, int T,
+                                                                   int V, int K, int cpw /* clips per workgroup */) {
+    extern __shared__ __attribute__((aligned(16))) char smq[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pad = (K - 1) / 2;
+    int cg = blockIdx.x, zi = blockIdx.z;          // XCD-aware numbering: the channel groups of a split share an L2
+    if ((gridDim.z & 7) == 0) {
+        const int L = blockIdx.x + gridDim.x * blockIdx.z;
+        zi = (L & 7) + 8 * (L / (8 * gridDim.x));
+        cg = (L >> 3) % gridDim.x;
+    }
+    const int c0 = cg * 32, o0 = blockIdx.y * 128;
+    // LDS: dz tile 0 (hi | lo) | dz tile 1 (hi | lo) | input ring (hi | lo)
+    constexpr int AIMG = 128 * WQ_PITCH_A, ATILE = 2 * AIMG, BIMG = 32 * WQ_PITCH_B;
+    char *Bring = smq + 2 * ATILE;
+    const int chunks = (T + WQ_TFM - 1) / WQ_TFM;
+    const int upc = chunks + WQ_LEAD;              // units per clip incl. the lead-in
+    const int clip0 = zi * cpw, clip1 = min(clip0 + cpw, N);
+    const int nun = (clip1 > clip0 ? clip1 - clip0 : 0) * upc;     // units of this workgroup
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    // ---- staging units of this lane: three dz pieces (row, frame, piece) and — lanes < 192 — one input piece ----------
+    int a_row[3], a_tt[3], a_uq[3], a_lds[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = tid + i * WQ_THREADS;        // < 768 = 128 rows x 6 pieces
+        a_row[i] = e / 6;
+        const int q = e - a_row[i] * 6;
+        a_tt[i] = q / 3;
+        a_uq[i] = q - a_tt[i] * 3;
+        a_lds[i] = a_row[i] * WQ_PITCH_A + q * 16;
+    }
+    const int be = min(tid, 191);
+    const int b_row = be / 6, b_ff = (be - b_row * 6) / 3, b_uq = be - b_row * 6 - b_ff * 3;
+    const bool b_live = tid < 192;
+    float pa[3][8], pb[8];
+    const unsigned clipA = (unsigned)((size_t)Cout * T * V * 4), clipB = (unsigned)((size_t)Cin * T * V * 4);
+    constexpr unsigned OOB = 0x7ffffff0u;
+    // unit g of this workgroup -> (clip, first output frame t0; t0 < 0: lead-in)
+    // (readfirstlane: the values are uniform, but unless hipcc KNOWS it every buffer load below becomes a waterfall loop over
+    //  the lanes' resource descriptors — 129 v_readfirstlane and 32 loops per unit in the first build)
+    auto unit_clip = [&](int g) { return __builtin_amdgcn_readfirstlane(clip0 + g / upc); };
+    auto unit_t0 = [&](int g) { return __builtin_amdgcn_readfirstlane((g % upc - WQ_LEAD) * WQ_TFM); };
+    auto load_a = [&](int i, bool live, int n, int t0) {
+        const __amdgpu_buffer_rsrc_t ra =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dz + (size_t)n * Cout * T * V), 0, clipA, 0x00020000);
+        const int t = t0 + a_tt[i];
+        const unsigned off = (live && t0 >= 0 && t < T) ? (unsigned)((((o0 + a_row[i]) * T + t) * V + a_uq[i] * 8) * 4) : OOB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float val = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, off + 4 * j, 0, 0));
+            pa[i][j] = (a_uq[i] * 8 + j < V) ? val : 0.f;
+        }
+    };
+    auto load_b = [&](bool live, int n, int t0) {
+        const __amdgpu_buffer_rsrc_t rb =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)n * Cin * T * V), 0, clipB, 0x00020000);
+        const int f = t0 - pad + (WQ_WIN - WQ_TFM) + b_ff;        // the unit's new frames: window frames 8, 9
+        const unsigned off = (live && f >= 0 && f < T) ? (unsigned)((((c0 + b_row) * T + f) * V + b_uq * 8) * 4) : OOB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float val = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, off + 4 * j, 0, 0));
+            pb[j] = (b_uq * 8 + j < V) ? val : 0.f;
+        }
+    };
+    auto store_a = [&](int i, char *atile) {
+        uint4 hi, lo;
+        split8(pa[i], hi, lo);
+        *reinterpret_cast<uint4 *>(atile + a_lds[i]) = hi;
+        if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(atile + AIMG + a_lds[i]) = lo;
+    };
+    // Ring position of a unit = 2 * (its index in this workgroup): it runs on across clips, so the slots a unit's new frames
+    // go to (positions 2g+8, 2g+9) never lie in the window of the unit being multiplied (2(g-1) .. 2(g-1)+9).
+    auto store_b = [&](int g) {                  // into the ring slots of unit g's new frames
+        const int slot = (2 * g + (WQ_WIN - WQ_TFM) + b_ff) & (WQ_RING - 1);
+        uint4 hi, lo;
+        split8(pb, hi, lo);
+        if (b_live) {
+            char *p = Bring + b_row * WQ_PITCH_B + slot * WQ_FRB + b_uq * 16;
+            *reinterpret_cast<uint4 *>(p) = hi;
+            if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(p + BIMG) = lo;
+        }
+    };
+
+    // ---- fragment addressing ---------------------------------------------------------------------------------------
+    // k-step ks, lane half h: piece q = 2 ks + h of the unit's 6 -> frame tt = q / 3, piece in frame uq = q % 3
+    const int h = lane >> 5;
+    const int a_lane = (wave * 32 + (lane & 31)) * WQ_PITCH_A + h * 16;          // + ks * 32
+    int b_lane[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) b_lane[ks] = (lane & 31) * WQ_PITCH_B + ((2 * ks + h) % 3) * 16;
+
+    // ---- prologue: ring zeroed (lead-in units multiply it by a zero dz tile: it must hold finite numbers), unit 0 staged,
+    //      unit 1 in the registers
+    for (int e = tid; e < 2 * BIMG / 16; e += WQ_THREADS) reinterpret_cast<uint4 *>(Bring)[e] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (nun > 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) load_a(i, true, unit_clip(0), unit_t0(0));
+        load_b(true, unit_clip(0), unit_t0(0));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) store_a(i, smq);
+        store_b(0);
+        const bool l1 = 1 < nun;
+        const int n1 = __builtin_amdgcn_readfirstlane(l1 ? unit_clip(1) : clip0), t1 = __builtin_amdgcn_readfirstlane(l1 ? unit_t0(1) : -1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) load_a(i, l1, n1, t1);
+        load_b(l1, n1, t1);
+    }
+    __syncthreads();
+
+    for (int g = 0; g < nun; ++g) {
+        const bool l2 = g + 2 < nun;              // the unit whose loads are issued during this one (all scalar)
+        const int n2 = __builtin_amdgcn_readfirstlane(l2 ? unit_clip(g + 2) : clip0), t2 = __builtin_amdgcn_readfirstlane(l2 ? unit_t0(g + 2) : -1);
+        char *acur = smq + (g & 1) * ATILE, *anxt = smq + ((g + 1) & 1) * ATILE;
+        // staging chunk c (0 .. 7) of this unit: store the held piece of unit g+1, then re-load its registers with unit g+2
+        auto chunk = [&](auto c_c) {
+            constexpr int c = decltype(c_c)::value;
+            if constexpr (c == 0) store_a(0, anxt);
+            if constexpr (c == 1) load_a(0, l2, n2, t2);
+            if constexpr (c == 2) store_a(1, anxt);
+            if constexpr (c == 3) load_a(1, l2, n2, t2);
+            if constexpr (c == 4) store_a(2, anxt);
+            if constexpr (c == 5) load_a(2, l2, n2, t2);
+            if constexpr (c == 6) { if (g + 1 < nun) store_b(g + 1); }
+            if constexpr (c == 7) load_b(l2, n2, t2);
+        };
+        {   // (lead-in units run the MFMAs as well, on an all-zero dz tile: a branch around them made hipcc shuffle the
+            //  144 accumulator registers at the join — 700 copies per unit)
+            // ring offsets of the window frames m = 0 .. 9 of this unit (scalar)
+            int so[10];
+#pragma unroll
+            for (int m = 0; m < 10; ++m) so[m] = ((2 * g + m) & (WQ_RING - 1)) * WQ_FRB;
+            auto b_addr = [&](auto ks_c, auto k_c) -> const char * {
+                constexpr int ks = decltype(ks_c)::value, k = decltype(k_c)::value;
+                // frame of the piece: ks = 0 -> 0, ks = 2 -> 1, ks = 1 -> the lane half
+                const int s_lo = so[k], s_hi = so[k + 1];
+                const int sel = ks == 0 ? s_lo : (ks == 2 ? s_hi : (h ? s_hi : s_lo));
+                return Bring + b_lane[ks] + sel;
+            };
+            uint4 bh[2][3], bl[2][3];
+            auto read_group = [&](auto ks_c, auto grp_c, auto set_c) {
+                constexpr int grp = decltype(grp_c)::value, set = decltype(set_c)::value;
+                static_forq<0, 3>([&](auto kk_c) {
+                    constexpr int kk = decltype(kk_c)::value;
+                    const char *p = b_addr(ks_c, std::integral_constant<int, grp * 3 + kk>{});
+                    bh[set][kk] = *reinterpret_cast<const uint4 *>(p);
+                    if constexpr (TERMS == 3) bl[set][kk] = *reinterpret_cast<const uint4 *>(p + BIMG);
+                });
+            };
+            using I0 = std::integral_constant<int, 0>;
+            read_group(I0{}, I0{}, I0{});
+            uint4 ahs[2], als[2];                 // dz fragments of a k-step, read one k-step ahead
+            ahs[0] = *reinterpret_cast<const uint4 *>(acur + a_lane);
+            als[0] = ahs[0];
+            if constexpr (TERMS == 3) als[0] = *reinterpret_cast<const uint4 *>(acur + AIMG + a_lane);
+            static_forq<0, 9>([&](auto s_c) {                   // 9 MFMA groups: (k-step, tap group)
+                constexpr int s = decltype(s_c)::value, ks = s / 3, grp = s % 3, set = s & 1;
+                if constexpr (grp == 0 && ks + 1 < 3) {
+                    ahs[(ks + 1) & 1] = *reinterpret_cast<const uint4 *>(acur + a_lane + (ks + 1) * 32);
+                    als[(ks + 1) & 1] = ahs[(ks + 1) & 1];
+                    if constexpr (TERMS == 3) als[(ks + 1) & 1] = *reinterpret_cast<const uint4 *>(acur + AIMG + a_lane + (ks + 1) * 32);
+                }
+                const uint4 ah = ahs[ks & 1], al = als[ks & 1];
+                if constexpr (s + 1 < 9)                       // the next group's fragments first
+                    read_group(std::integral_constant<int, (s + 1) / 3>{}, std::integral_constant<int, (s + 1) % 3>{},
+                               std::integral_constant<int, (s + 1) & 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    if constexpr (TERMS == 3) {
+                        acc[grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[set][kk]), acc[grp * 3 + kk], 0, 0, 0);
+                        acc[grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[set][kk]), acc[grp * 3 + kk], 0, 0, 0);
+                    }
+                    acc[grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[set][kk]), acc[grp * 3 + kk], 0, 0, 0);
+                    // (no AGPR pin here: with 32x32 accumulators it made hipcc copy every block in and out)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s < 8) chunk(s_c);               // staging between the MFMA groups
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        __syncthreads();                          // unit g+1 is staged; tile g & 1 and the ring slots behind the window are free
+    }
+
+    // D[row = o][col = c]: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float *dst = part + (size_t)zi * Cout * Cin * K;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (k < K) {                              // (taps beyond K were computed on real (finite) frames and are dropped)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (o < Cout) dst[((size_t)o * Cin + c0 + (lane & 31)) * K + k] = acc[k][r];   // (rows >= Cout: dz read as zeros)
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool tcn_wgrad_v6_supported(int N, int Cin, int Cout, int T, int V, int K, int stride) {
+    if (stride != 1 || K < 1 || K > 9 || (K & 1) == 0) return false;
+    if ((Cout % 128 != 0 && Cout != 64) || Cin % 32 != 0) return false;
+    if (V < 17 || V > WQ_VP || N < 1 || T < 1) return false;
+    if ((size_t)(Cin > Cout ? Cin : Cout) * T * V * 4 >= ((size_t)1 << 31)) return false;   // per-clip buffer resources
+    return true;
+}
+
+int tcn_wgrad_v6_splits(int N, int Cin, int Cout) {
+    const int wgs = (Cin / 32) * ceil_div(Cout, 128);
+    int splits = 256 / wgs;                       // about one workgroup per CU
+    if (splits < 1) splits = 1;
+    if (splits > N) splits = N;
+    return splits;
+}
+
+// partial sums: part[splits][Cout][Cin][K] (the caller sums them in a fixed order)
+int launch_tcn_wgrad_v6(const float *dz, const float *x, float *part, int N, int Cin, int Cout, int T, int V, int K, unsigned flags,
+                        hipStream_t st) {
+    const unsigned math = flags & STGCN_MATH_MASK;
+    const int splits = tcn_wgrad_v6_splits(N, Cin, Cout);
+    const int cpw = ceil_div(N, splits);
+    const dim3 grid(Cin / 32, ceil_div(Cout, 128), splits);
+    const size_t lds = (size_t)2 * 2 * 128 * WQ_PITCH_A + (size_t)2 * 32 * WQ_PITCH_B;
+    if (math == STGCN_MATH_BF16X3) {
+        STGCN_HIP_CHECK(allow_lds((tcn_wgrad_v6_kernel<3>), lds));
+        hipLaunchKernelGGL((tcn_wgrad_v6_kernel<3>), grid, dim3(WQ_THREADS), lds, st, dz, x, part, N, Cin, Cout, T, V, K, cpw);
+    } else {
+        STGCN_HIP_CHECK(allow_lds((tcn_wgrad_v6_kernel<1>), lds));
+        hipLaunchKernelGGL((tcn_wgrad_v6_kernel<1>), grid, dim3(WQ_THREADS), lds, st, dz, x, part, N, Cin, Cout, T, V, K, cpw);
+    }
+    STGCN_LAUNCH_CHECK("tcn_wgrad_v6_kernel");
+    return STGCN_OK;
+}
+
+}  // namespace stgcn

@@ -44,10 +44,15 @@ __device__ __forceinline__ void static_forq(F &&f) {
     }
 }
 
-template <int TERMS>
+// NOB: 32-channel dz blocks per wave.  NOB = 1: wave w = block w, 32 input channels per workgroup.  NOB = 2: wave w = blocks
+// 2 (w & 1), +1 and input-channel block w >> 1 of a 64-channel group — every input fragment read then feeds two blocks: with
+// NOB = 1 the LDS moved 80 KiB per k-step for 864 cycles of MFMAs (640 cycles of its bandwidth before any conflict) and
+// bound the kernel.
+template <int TERMS, int NOB>
 __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *__restrict__ dz, const float *__restrict__ x,
                                                                    float *__restrict__ part, int N, int Cin, int Cout, int T,
                                                                    int V, int K, int cpw /* clips per workgroup */) {
+    // (no run-time ablation switches in here: inside the unrolled MFMA groups they tripled the kernel's time)
     extern __shared__ __attribute__((aligned(16))) char smq[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,20 +63,24 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
         zi = (L & 7) + 8 * (L / (8 * gridDim.x));
         cg = (L >> 3) % gridDim.x;
     }
-    const int c0 = cg * 32, o0 = blockIdx.y * 128;
+    constexpr int CB = NOB;                        // 32-channel input blocks per workgroup
+    const int c0 = cg * 32 * CB, o0 = blockIdx.y * 128;
+    const int ob0 = NOB == 1 ? wave : (wave & 1) * 2, cb = NOB == 1 ? 0 : wave >> 1;
     // LDS: dz tile 0 (hi | lo) | dz tile 1 (hi | lo) | input ring (hi | lo)
-    constexpr int AIMG = 128 * WQ_PITCH_A, ATILE = 2 * AIMG, BIMG = 32 * WQ_PITCH_B;
+    constexpr int AIMG = 128 * WQ_PITCH_A, ATILE = 2 * AIMG, BIMG = 32 * CB * WQ_PITCH_B;
     char *Bring = smq + 2 * ATILE;
     const int chunks = (T + WQ_TFM - 1) / WQ_TFM;
     const int upc = chunks + WQ_LEAD;              // units per clip incl. the lead-in
     const int clip0 = zi * cpw, clip1 = min(clip0 + cpw, N);
     const int nun = (clip1 > clip0 ? clip1 - clip0 : 0) * upc;     // units of this workgroup
 
-    f32x16 acc[9];
+    f32x16 acc[NOB][9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int b = 0; b < NOB; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][k][r] = 0.f;
 
     // ---- staging units of this lane: three dz pieces (row, frame, piece) and — lanes < 192 — one input piece ----------
     int a_row[3], a_tt[3], a_uq[3], a_lds[3];
@@ -84,10 +93,18 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
         a_uq[i] = q - a_tt[i] * 3;
         a_lds[i] = a_row[i] * WQ_PITCH_A + q * 16;
     }
-    const int be = min(tid, 191);
-    const int b_row = be / 6, b_ff = (be - b_row * 6) / 3, b_uq = be - b_row * 6 - b_ff * 3;
-    const bool b_live = tid < 192;
-    float pa[3][8], pb[8];
+    int b_row[CB], b_ff[CB], b_uq[CB];
+    bool b_live[CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const int e = tid + j * WQ_THREADS;        // < 192 * CB = 32 * CB rows x 6 pieces
+        b_live[j] = e < 192 * CB;
+        const int be = min(e, 192 * CB - 1);
+        b_row[j] = be / 6;
+        b_ff[j] = (be - b_row[j] * 6) / 3;
+        b_uq[j] = be - b_row[j] * 6 - b_ff[j] * 3;
+    }
+    float pa[3][8], pb[CB][8];
     const unsigned clipA = (unsigned)((size_t)Cout * T * V * 4), clipB = (unsigned)((size_t)Cin * T * V * 4);
     constexpr unsigned OOB = 0x7ffffff0u;
     // unit g of this workgroup -> (clip, first output frame t0; t0 < 0: lead-in)
@@ -109,12 +126,15 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
     auto load_b = [&](bool live, int n, int t0) {
         const __amdgpu_buffer_rsrc_t rb =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)n * Cin * T * V), 0, clipB, 0x00020000);
-        const int f = t0 - pad + (WQ_WIN - WQ_TFM) + b_ff;        // the unit's new frames: window frames 8, 9
-        const unsigned off = (live && f >= 0 && f < T) ? (unsigned)((((c0 + b_row) * T + f) * V + b_uq * 8) * 4) : OOB;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float val = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, off + 4 * j, 0, 0));
-            pb[j] = (b_uq * 8 + j < V) ? val : 0.f;
+        for (int q = 0; q < CB; ++q) {
+            const int f = t0 - pad + (WQ_WIN - WQ_TFM) + b_ff[q];     // the unit's new frames: window frames 8, 9
+            const unsigned off = (live && f >= 0 && f < T) ? (unsigned)((((c0 + b_row[q]) * T + f) * V + b_uq[q] * 8) * 4) : OOB;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float val = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, off + 4 * j, 0, 0));
+                pb[q][j] = (b_uq[q] * 8 + j < V) ? val : 0.f;
+            }
         }
     };
     auto store_a = [&](int i, char *atile) {
@@ -126,23 +146,26 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
     // Ring position of a unit = 2 * (its index in this workgroup): it runs on across clips, so the slots a unit's new frames
     // go to (positions 2g+8, 2g+9) never lie in the window of the unit being multiplied (2(g-1) .. 2(g-1)+9).
     auto store_b = [&](int g) {                  // into the ring slots of unit g's new frames
-        const int slot = (2 * g + (WQ_WIN - WQ_TFM) + b_ff) & (WQ_RING - 1);
-        uint4 hi, lo;
-        split8(pb, hi, lo);
-        if (b_live) {
-            char *p = Bring + b_row * WQ_PITCH_B + slot * WQ_FRB + b_uq * 16;
-            *reinterpret_cast<uint4 *>(p) = hi;
-            if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(p + BIMG) = lo;
+#pragma unroll
+        for (int q = 0; q < CB; ++q) {
+            const int slot = (2 * g + (WQ_WIN - WQ_TFM) + b_ff[q]) & (WQ_RING - 1);
+            uint4 hi, lo;
+            split8(pb[q], hi, lo);
+            if (b_live[q]) {
+                char *p = Bring + b_row[q] * WQ_PITCH_B + slot * WQ_FRB + b_uq[q] * 16;
+                *reinterpret_cast<uint4 *>(p) = hi;
+                if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(p + BIMG) = lo;
+            }
         }
     };
 
     // ---- fragment addressing ---------------------------------------------------------------------------------------
     // k-step ks, lane half h: piece q = 2 ks + h of the unit's 6 -> frame tt = q / 3, piece in frame uq = q % 3
     const int h = lane >> 5;
-    const int a_lane = (wave * 32 + (lane & 31)) * WQ_PITCH_A + h * 16;          // + ks * 32
+    const int a_lane = (ob0 * 32 + (lane & 31)) * WQ_PITCH_A + h * 16;           // + ks * 32  (+ 32 rows for the second block)
     int b_lane[3];
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) b_lane[ks] = (lane & 31) * WQ_PITCH_B + ((2 * ks + h) % 3) * 16;
+    for (int ks = 0; ks < 3; ++ks) b_lane[ks] = (cb * 32 + (lane & 31)) * WQ_PITCH_B + ((2 * ks + h) % 3) * 16;
 
     // ---- prologue: ring zeroed (lead-in units multiply it by a zero dz tile: it must hold finite numbers), unit 0 staged,
     //      unit 1 in the registers
@@ -204,30 +227,39 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
             };
             using I0 = std::integral_constant<int, 0>;
             read_group(I0{}, I0{}, I0{});
-            uint4 ahs[2], als[2];                 // dz fragments of a k-step, read one k-step ahead
-            ahs[0] = *reinterpret_cast<const uint4 *>(acur + a_lane);
-            als[0] = ahs[0];
-            if constexpr (TERMS == 3) als[0] = *reinterpret_cast<const uint4 *>(acur + AIMG + a_lane);
+            uint4 ahs[2][NOB], als[2][NOB];       // dz fragments of a k-step, read one k-step ahead
+#pragma unroll
+            for (int b = 0; b < NOB; ++b) {
+                ahs[0][b] = *reinterpret_cast<const uint4 *>(acur + a_lane + b * 32 * WQ_PITCH_A);
+                als[0][b] = ahs[0][b];
+                if constexpr (TERMS == 3) als[0][b] = *reinterpret_cast<const uint4 *>(acur + AIMG + a_lane + b * 32 * WQ_PITCH_A);
+            }
             static_forq<0, 9>([&](auto s_c) {                   // 9 MFMA groups: (k-step, tap group)
                 constexpr int s = decltype(s_c)::value, ks = s / 3, grp = s % 3, set = s & 1;
                 if constexpr (grp == 0 && ks + 1 < 3) {
-                    ahs[(ks + 1) & 1] = *reinterpret_cast<const uint4 *>(acur + a_lane + (ks + 1) * 32);
-                    als[(ks + 1) & 1] = ahs[(ks + 1) & 1];
-                    if constexpr (TERMS == 3) als[(ks + 1) & 1] = *reinterpret_cast<const uint4 *>(acur + AIMG + a_lane + (ks + 1) * 32);
+#pragma unroll
+                    for (int b = 0; b < NOB; ++b) {
+                        ahs[(ks + 1) & 1][b] = *reinterpret_cast<const uint4 *>(acur + a_lane + b * 32 * WQ_PITCH_A + (ks + 1) * 32);
+                        als[(ks + 1) & 1][b] = ahs[(ks + 1) & 1][b];
+                        if constexpr (TERMS == 3)
+                            als[(ks + 1) & 1][b] = *reinterpret_cast<const uint4 *>(acur + AIMG + a_lane + b * 32 * WQ_PITCH_A + (ks + 1) * 32);
+                    }
                 }
-                const uint4 ah = ahs[ks & 1], al = als[ks & 1];
                 if constexpr (s + 1 < 9)                       // the next group's fragments first
                     read_group(std::integral_constant<int, (s + 1) / 3>{}, std::integral_constant<int, (s + 1) % 3>{},
                                std::integral_constant<int, (s + 1) & 1>{});
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kk = 0; kk < 3; ++kk) {
-                    if constexpr (TERMS == 3) {
-                        acc[grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[set][kk]), acc[grp * 3 + kk], 0, 0, 0);
-                        acc[grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[set][kk]), acc[grp * 3 + kk], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < NOB; ++b) {
+                        const uint4 ah = ahs[ks & 1][b], al = als[ks & 1][b];
+                        if constexpr (TERMS == 3) {
+                            acc[b][grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[set][kk]), acc[b][grp * 3 + kk], 0, 0, 0);
+                            acc[b][grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[set][kk]), acc[b][grp * 3 + kk], 0, 0, 0);
+                        }
+                        acc[b][grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[set][kk]), acc[b][grp * 3 + kk], 0, 0, 0);
                     }
-                    acc[grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[set][kk]), acc[grp * 3 + kk], 0, 0, 0);
-                    // (no AGPR pin here: with 32x32 accumulators it made hipcc copy every block in and out)
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (s < 8) chunk(s_c);               // staging between the MFMA groups
@@ -240,12 +272,15 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
     // D[row = o][col = c]: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float *dst = part + (size_t)zi * Cout * Cin * K;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        if (k < K) {                              // (taps beyond K were computed on real (finite) frames and are dropped)
+    for (int b = 0; b < NOB; ++b) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = o0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (o < Cout) dst[((size_t)o * Cin + c0 + (lane & 31)) * K + k] = acc[k][r];   // (rows >= Cout: dz read as zeros)
+        for (int k = 0; k < 9; ++k) {
+            if (k < K) {                          // (taps beyond K were computed on real (finite) frames and are dropped)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = o0 + (ob0 + b) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (o < Cout) dst[((size_t)o * Cin + c0 + cb * 32 + (lane & 31)) * K + k] = acc[b][k][r];   // (rows >= Cout: dz read as zeros)
+                }
             }
         }
     }
@@ -261,8 +296,11 @@ bool tcn_wgrad_v6_supported(int N, int Cin, int Cout, int T, int V, int K, int s
     return true;
 }
 
+// two dz blocks per wave (64 input channels per workgroup) where the shape allows  (diagnostic builds: STGCN_ABLATE=4 off)
+static bool wgrad_v6_two_blocks(int Cin, int Cout) { return Cin % 64 == 0 && Cout % 128 == 0 && !(ablate_mask() & 4); }
+
 int tcn_wgrad_v6_splits(int N, int Cin, int Cout) {
-    const int wgs = (Cin / 32) * ceil_div(Cout, 128);
+    const int wgs = (Cin / (wgrad_v6_two_blocks(Cin, Cout) ? 64 : 32)) * ceil_div(Cout, 128);
     int splits = 256 / wgs;                       // about one workgroup per CU
     if (splits < 1) splits = 1;
     if (splits > N) splits = N;
@@ -275,15 +313,18 @@ int launch_tcn_wgrad_v6(const float *dz, const float *x, float *part, int N, int
     const unsigned math = flags & STGCN_MATH_MASK;
     const int splits = tcn_wgrad_v6_splits(N, Cin, Cout);
     const int cpw = ceil_div(N, splits);
-    const dim3 grid(Cin / 32, ceil_div(Cout, 128), splits);
-    const size_t lds = (size_t)2 * 2 * 128 * WQ_PITCH_A + (size_t)2 * 32 * WQ_PITCH_B;
-    if (math == STGCN_MATH_BF16X3) {
-        STGCN_HIP_CHECK(allow_lds((tcn_wgrad_v6_kernel<3>), lds));
-        hipLaunchKernelGGL((tcn_wgrad_v6_kernel<3>), grid, dim3(WQ_THREADS), lds, st, dz, x, part, N, Cin, Cout, T, V, K, cpw);
-    } else {
-        STGCN_HIP_CHECK(allow_lds((tcn_wgrad_v6_kernel<1>), lds));
-        hipLaunchKernelGGL((tcn_wgrad_v6_kernel<1>), grid, dim3(WQ_THREADS), lds, st, dz, x, part, N, Cin, Cout, T, V, K, cpw);
-    }
+    const bool two = wgrad_v6_two_blocks(Cin, Cout);
+    const dim3 grid(Cin / (two ? 64 : 32), ceil_div(Cout, 128), splits);
+    const size_t lds = (size_t)2 * 2 * 128 * WQ_PITCH_A + (size_t)2 * 32 * (two ? 2 : 1) * WQ_PITCH_B;
+#define LAUNCH_WQ(TERMS, NOB)                                                                                         \
+    do {                                                                                                              \
+        STGCN_HIP_CHECK(allow_lds((tcn_wgrad_v6_kernel<TERMS, NOB>), lds));                                           \
+        hipLaunchKernelGGL((tcn_wgrad_v6_kernel<TERMS, NOB>), grid, dim3(WQ_THREADS), lds, st, dz, x, part, N, Cin, Cout, T, V, K, \
+                           cpw);                                                                                                    \
+    } while (0)
+    if (math == STGCN_MATH_BF16X3) { if (two) LAUNCH_WQ(3, 2); else LAUNCH_WQ(3, 1); }
+    else { if (two) LAUNCH_WQ(1, 2); else LAUNCH_WQ(1, 1); }
+#undef LAUNCH_WQ
     STGCN_LAUNCH_CHECK("tcn_wgrad_v6_kernel");
     return STGCN_OK;
 }

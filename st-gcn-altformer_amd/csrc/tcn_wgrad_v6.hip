@@ -74,7 +74,11 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
     const int clip0 = zi * cpw, clip1 = min(clip0 + cpw, N);
     const int nun = (clip1 > clip0 ? clip1 - clip0 : 0) * upc;     // units of this workgroup
 
-    f32x16 acc[NOB][9];
+    f32x16 acc[NOB][9], acc8[NOB];                // (acc8: tap 8 of the two-block form, kept in VGPRs — see the MFMA loop)
+#pragma unroll
+    for (int b = 0; b < NOB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc8[b][r] = 0.f;
 #pragma unroll
     for (int b = 0; b < NOB; ++b)
 #pragma unroll
@@ -249,18 +253,29 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
                     read_group(std::integral_constant<int, (s + 1) / 3>{}, std::integral_constant<int, (s + 1) % 3>{},
                                std::integral_constant<int, (s + 1) & 1>{});
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
-#pragma unroll
-                    for (int b = 0; b < NOB; ++b) {
-                        const uint4 ah = ahs[ks & 1][b], al = als[ks & 1][b];
-                        if constexpr (TERMS == 3) {
-                            acc[b][grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[set][kk]), acc[b][grp * 3 + kk], 0, 0, 0);
-                            acc[b][grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[set][kk]), acc[b][grp * 3 + kk], 0, 0, 0);
-                        }
-                        acc[b][grp * 3 + kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[set][kk]), acc[b][grp * 3 + kk], 0, 0, 0);
+                // one MFMA of term `term` (0: hi x lo, 1: lo x hi, 2: hi x hi) of (block b, tap grp*3 + kk)
+                auto mfma1 = [&](auto kk_c, auto b_c, auto term_c) {
+                    constexpr int kk = decltype(kk_c)::value, b = decltype(b_c)::value, term = decltype(term_c)::value, tap = grp * 3 + kk;
+                    const uint4 av = term == 1 ? als[ks & 1][b] : ahs[ks & 1][b];
+                    const uint4 bv = term == 0 ? bl[set][kk] : bh[set][kk];
+                    if constexpr (NOB == 2 && tap == 8) {
+                        // 2 x 9 accumulators are 288 registers, 32 more than the AGPR file: through the builtin hipcc rotated
+                        // blocks between the two files (850 copies per unit).  The last tap's accumulators live in VGPRs,
+                        // multiplied by VGPR-form MFMAs (inline asm; the only other reader is the epilogue).
+                        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+                        const u32x4 a4 = __builtin_bit_cast(u32x4, av), b4 = __builtin_bit_cast(u32x4, bv);
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc8[b]) : "v"(a4), "v"(b4));
+                    } else {
+                        acc[b][tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[b][tap], 0, 0, 0);
                     }
-                }
+                };
+                // order: consecutive MFMAs go to different accumulators (the three terms of one block are a dependent chain)
+                static_forq<0, (TERMS == 3 ? 3 : 1)>([&](auto t_c) {
+                    using TC = std::integral_constant<int, (TERMS == 3 ? decltype(t_c)::value : 2)>;
+                    static_forq<0, 3>([&](auto kk_c) {
+                        static_forq<0, NOB>([&](auto b_c) { mfma1(kk_c, b_c, TC{}); });
+                    });
+                });
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (s < 8) chunk(s_c);               // staging between the MFMA groups
                 __builtin_amdgcn_sched_barrier(0);
@@ -279,7 +294,8 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int o = o0 + (ob0 + b) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (o < Cout) dst[((size_t)o * Cin + c0 + cb * 32 + (lane & 31)) * K + k] = acc[b][k][r];   // (rows >= Cout: dz read as zeros)
+                    const float val = (NOB == 2 && k == 8) ? acc8[b][r] : acc[b][k][r];
+                    if (o < Cout) dst[((size_t)o * Cin + c0 + cb * 32 + (lane & 31)) * K + k] = val;   // (rows >= Cout: dz read as zeros)
                 }
             }
         }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
         a_uq[i] = q - a_tt[i] * 3;
         a_lds[i] = a_row[i] * WQ_PITCH_A + q * 16;
     }
-    int b_row[CB], b_ff[CB], b_uq[CB];
+    int b_row[CB], b_ff[CB], b_uq[CB], b_nv[CB];
     bool b_live[CB];
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
         b_row[j] = be / 6;
         b_ff[j] = (be - b_row[j] * 6) / 3;
         b_uq[j] = be - b_row[j] * 6 - b_ff[j] * 3;
+        b_nv[j] = V - b_uq[j] * 8;              // valid columns of the piece
     }
     float pa[3][8], pb[CB][8];
     const unsigned clipA = (unsigned)((size_t)Cout * T * V * 4), clipB = (unsigned)((size_t)Cin * T * V * 4);
@@ -116,30 +117,42 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
     //  the lanes' resource descriptors — 129 v_readfirstlane and 32 loops per unit in the first build)
     auto unit_clip = [&](int g) { return __builtin_amdgcn_readfirstlane(clip0 + g / upc); };
     auto unit_t0 = [&](int g) { return __builtin_amdgcn_readfirstlane((g % upc - WQ_LEAD) * WQ_TFM); };
-    auto load_a = [&](int i, bool live, int n, int t0) {
-        const __amdgpu_buffer_rsrc_t ra =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dz + (size_t)n * Cout * T * V), 0, clipA, 0x00020000);
+    // dz pieces are NOT masked beyond column V: the padded columns of a frame only ever meet the same columns of an input frame,
+    // which are zeroed below (what dz holds there is the next row's first pixels or, past the clip, the resource's zeros).
+    auto a_off = [&](int i, bool live, int t0) -> unsigned {
         const int t = t0 + a_tt[i];
-        const unsigned off = (live && t0 >= 0 && t < T) ? (unsigned)((((o0 + a_row[i]) * T + t) * V + a_uq[i] * 8) * 4) : OOB;
+        return (live && t0 >= 0 && t < T) ? (unsigned)((((o0 + a_row[i]) * T + t) * V + a_uq[i] * 8) * 4) : OOB;
+    };
+    auto a_rsrc = [&](int n) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dz + (size_t)n * Cout * T * V), 0, clipA, 0x00020000);
+    };
+    auto b_off = [&](int q, bool live, int t0) -> unsigned {
+        const int f = t0 - pad + (WQ_WIN - WQ_TFM) + b_ff[q];         // the unit's new frames: window frames 8, 9
+        return (live && f >= 0 && f < T) ? (unsigned)((((c0 + b_row[q]) * T + f) * V + b_uq[q] * 8) * 4) : OOB;
+    };
+    auto b_rsrc = [&](int n) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)n * Cin * T * V), 0, clipB, 0x00020000);
+    };
+    auto load4 = [&](float *dst, __amdgpu_buffer_rsrc_t r, unsigned off) {      // (hipcc merges the four into one dwordx4)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float val = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, off + 4 * j, 0, 0));
-            pa[i][j] = (a_uq[i] * 8 + j < V) ? val : 0.f;
-        }
+        for (int j = 0; j < 4; ++j) dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off + 4 * j, 0, 0));
+    };
+    auto load_a = [&](int i, bool live, int n, int t0) {
+        const unsigned off = a_off(i, live, t0);
+        load4(&pa[i][0], a_rsrc(n), off);
+        load4(&pa[i][4], a_rsrc(n), off + 16);
     };
     auto load_b = [&](bool live, int n, int t0) {
-        const __amdgpu_buffer_rsrc_t rb =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)n * Cin * T * V), 0, clipB, 0x00020000);
 #pragma unroll
         for (int q = 0; q < CB; ++q) {
-            const int f = t0 - pad + (WQ_WIN - WQ_TFM) + b_ff[q];     // the unit's new frames: window frames 8, 9
-            const unsigned off = (live && f >= 0 && f < T) ? (unsigned)((((c0 + b_row[q]) * T + f) * V + b_uq[q] * 8) * 4) : OOB;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float val = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, off + 4 * j, 0, 0));
-                pb[q][j] = (b_uq[q] * 8 + j < V) ? val : 0.f;
-            }
+            const unsigned off = b_off(q, live, t0);
+            load4(&pb[q][0], b_rsrc(n), off);
+            load4(&pb[q][4], b_rsrc(n), off + 16);
         }
+    };
+    auto mask_b = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[q][j] = (j < b_nv[q]) ? pb[q][j] : 0.f;
     };
     auto store_a = [&](int i, char *atile) {
         uint4 hi, lo;
@@ -154,6 +167,7 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
         for (int q = 0; q < CB; ++q) {
             const int slot = (2 * g + (WQ_WIN - WQ_TFM) + b_ff[q]) & (WQ_RING - 1);
             uint4 hi, lo;
+            mask_b(q);
             split8(pb[q], hi, lo);
             if (b_live[q]) {
                 char *p = Bring + b_row[q] * WQ_PITCH_B + slot * WQ_FRB + b_uq[q] * 16;
@@ -194,17 +208,46 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
         const bool l2 = g + 2 < nun;              // the unit whose loads are issued during this one (all scalar)
         const int n2 = __builtin_amdgcn_readfirstlane(l2 ? unit_clip(g + 2) : clip0), t2 = __builtin_amdgcn_readfirstlane(l2 ? unit_t0(g + 2) : -1);
         char *acur = smq + (g & 1) * ATILE, *anxt = smq + ((g + 1) & 1) * ATILE;
-        // staging chunk c (0 .. 7) of this unit: store the held piece of unit g+1, then re-load its registers with unit g+2
-        auto chunk = [&](auto c_c) {
-            constexpr int c = decltype(c_c)::value;
-            if constexpr (c == 0) store_a(0, anxt);
-            if constexpr (c == 1) load_a(0, l2, n2, t2);
-            if constexpr (c == 2) store_a(1, anxt);
-            if constexpr (c == 3) load_a(1, l2, n2, t2);
-            if constexpr (c == 4) store_a(2, anxt);
-            if constexpr (c == 5) load_a(2, l2, n2, t2);
-            if constexpr (c == 6) { if (g + 1 < nun) store_b(g + 1); }
-            if constexpr (c == 7) load_b(l2, n2, t2);
+        // Staging of unit g+1 (convert + LDS stores) and the loads of unit g+2, cut into PIECES of a few instructions that go
+        // into the slots after the MFMAs (an MFMA occupies the pipe for 32 cycles; instructions placed right behind it issue
+        // meanwhile — clumped between the groups they left the pipe idle for a quarter of the unit).  Piece list, in order:
+        //   per dz register set i = 0..2 (9 pieces): pack pair 0..3 | write hi | write lo | offset | load 0..3 | load 4..7
+        //   per input set q (6 pieces):              pack pair 0..3 (columns >= V zeroed) | write hi | write lo
+        //   per input set q (3 pieces):              offset | load 0..3 | load 4..7
+        unsigned sh[4], sl[4], goff = OOB;
+        const __amdgpu_buffer_rsrc_t ra2 = a_rsrc(n2), rb2 = b_rsrc(n2);
+        constexpr int NP = 27 + 9 * CB;
+        auto pack_pair = [&](const float *v, int pr, int nv) {
+            const float v0 = (2 * pr < nv) ? v[2 * pr] : 0.f, v1 = (2 * pr + 1 < nv) ? v[2 * pr + 1] : 0.f;
+            sh[pr] = pack_bf16x2(v0, v1);
+            if constexpr (TERMS == 3) sl[pr] = pack_bf16x2(v0 - bf16_lo_to_f32(sh[pr]), v1 - bf16_hi_to_f32(sh[pr]));
+        };
+        auto piece = [&](auto p_c) __attribute__((always_inline)) {
+            constexpr int P = decltype(p_c)::value;
+            if constexpr (P < 27) {
+                constexpr int i = P / 9, r = P % 9;
+                if constexpr (r < 4) pack_pair(pa[i], r, 8);
+                else if constexpr (r == 4) *reinterpret_cast<uint4 *>(anxt + a_lds[i]) = make_uint4(sh[0], sh[1], sh[2], sh[3]);
+                else if constexpr (r == 5) { if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(anxt + AIMG + a_lds[i]) = make_uint4(sl[0], sl[1], sl[2], sl[3]); }
+                else if constexpr (r == 6) goff = a_off(i, l2, t2);
+                else if constexpr (r == 7) load4(&pa[i][0], ra2, goff);
+                else load4(&pa[i][4], ra2, goff + 16);
+            } else if constexpr (P < 27 + 6 * CB) {
+                constexpr int q = (P - 27) / 6, r = (P - 27) % 6;
+                if constexpr (r < 4) pack_pair(pb[q], r, b_nv[q]);
+                else {
+                    // ring slots of unit g+1's new frames (past the last unit they take zeros nobody reads)
+                    const int slot = (2 * (g + 1) + (WQ_WIN - WQ_TFM) + b_ff[q]) & (WQ_RING - 1);
+                    char *dp = Bring + b_row[q] * WQ_PITCH_B + slot * WQ_FRB + b_uq[q] * 16;
+                    if constexpr (r == 4) { if (b_live[q]) *reinterpret_cast<uint4 *>(dp) = make_uint4(sh[0], sh[1], sh[2], sh[3]); }
+                    else if constexpr (TERMS == 3) { if (b_live[q]) *reinterpret_cast<uint4 *>(dp + BIMG) = make_uint4(sl[0], sl[1], sl[2], sl[3]); }
+                }
+            } else {
+                constexpr int q = (P - 27 - 6 * CB) / 3, r = (P - 27 - 6 * CB) % 3;
+                if constexpr (r == 0) goff = b_off(q, l2, t2);
+                else if constexpr (r == 1) load4(&pb[q][0], rb2, goff);
+                else load4(&pb[q][4], rb2, goff + 16);
+            }
         };
         {   // (lead-in units run the MFMAs as well, on an all-zero dz tile: a branch around them made hipcc shuffle the
             //  144 accumulator registers at the join — 700 copies per unit)
@@ -240,21 +283,33 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
             }
             static_forq<0, 9>([&](auto s_c) {                   // 9 MFMA groups: (k-step, tap group)
                 constexpr int s = decltype(s_c)::value, ks = s / 3, grp = s % 3, set = s & 1;
-                if constexpr (grp == 0 && ks + 1 < 3) {
-#pragma unroll
-                    for (int b = 0; b < NOB; ++b) {
-                        ahs[(ks + 1) & 1][b] = *reinterpret_cast<const uint4 *>(acur + a_lane + b * 32 * WQ_PITCH_A + (ks + 1) * 32);
-                        als[(ks + 1) & 1][b] = ahs[(ks + 1) & 1][b];
-                        if constexpr (TERMS == 3)
-                            als[(ks + 1) & 1][b] = *reinterpret_cast<const uint4 *>(acur + AIMG + a_lane + b * 32 * WQ_PITCH_A + (ks + 1) * 32);
+                // fillers of this group: the next group's input fragments (6 reads), the next k-step's dz fragments (2 per
+                // block, at the k-step's first group), then this group's share of the staging pieces
+                constexpr int NRB = s + 1 < 9 ? 3 * (TERMS == 3 ? 2 : 1) : 0;
+                constexpr int NRA = (grp == 0 && ks + 1 < 3) ? NOB * (TERMS == 3 ? 2 : 1) : 0;
+                constexpr int P0 = s * NP / 9, P1 = (s + 1) * NP / 9;
+                constexpr int NF = NRB + NRA + (P1 - P0);
+                constexpr int NM = (TERMS == 3 ? 3 : 1) * 3 * NOB;
+                auto filler = [&](auto f_c) __attribute__((always_inline)) {
+                    constexpr int f = decltype(f_c)::value;
+                    if constexpr (f < NRB) {
+                        constexpr int kk = f % 3, lo = f / 3, s1 = s + 1;
+                        const char *p = b_addr(std::integral_constant<int, s1 / 3>{}, std::integral_constant<int, (s1 % 3) * 3 + kk>{});
+                        if constexpr (lo == 0) bh[s1 & 1][kk] = *reinterpret_cast<const uint4 *>(p);
+                        else bl[s1 & 1][kk] = *reinterpret_cast<const uint4 *>(p + BIMG);
+                    } else if constexpr (f < NRB + NRA) {
+                        constexpr int b = (f - NRB) % NOB, lo = (f - NRB) / NOB, k1 = ks + 1;
+                        const char *p = acur + a_lane + b * 32 * WQ_PITCH_A + k1 * 32;
+                        if constexpr (lo == 0) {
+                            ahs[k1 & 1][b] = *reinterpret_cast<const uint4 *>(p);
+                            if constexpr (TERMS != 3) als[k1 & 1][b] = ahs[k1 & 1][b];
+                        } else als[k1 & 1][b] = *reinterpret_cast<const uint4 *>(p + AIMG);
+                    } else {
+                        piece(std::integral_constant<int, P0 + f - NRB - NRA>{});
                     }
-                }
-                if constexpr (s + 1 < 9)                       // the next group's fragments first
-                    read_group(std::integral_constant<int, (s + 1) / 3>{}, std::integral_constant<int, (s + 1) % 3>{},
-                               std::integral_constant<int, (s + 1) & 1>{});
-                __builtin_amdgcn_sched_barrier(0);
+                };
                 // one MFMA of term `term` (0: hi x lo, 1: lo x hi, 2: hi x hi) of (block b, tap grp*3 + kk)
-                auto mfma1 = [&](auto kk_c, auto b_c, auto term_c) {
+                auto mfma1 = [&](auto kk_c, auto b_c, auto term_c) __attribute__((always_inline)) {
                     constexpr int kk = decltype(kk_c)::value, b = decltype(b_c)::value, term = decltype(term_c)::value, tap = grp * 3 + kk;
                     const uint4 av = term == 1 ? als[ks & 1][b] : ahs[ks & 1][b];
                     const uint4 bv = term == 0 ? bl[set][kk] : bh[set][kk];
@@ -269,16 +324,15 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
                         acc[b][tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[b][tap], 0, 0, 0);
                     }
                 };
-                // order: consecutive MFMAs go to different accumulators (the three terms of one block are a dependent chain)
-                static_forq<0, (TERMS == 3 ? 3 : 1)>([&](auto t_c) {
-                    using TC = std::integral_constant<int, (TERMS == 3 ? decltype(t_c)::value : 2)>;
-                    static_forq<0, 3>([&](auto kk_c) {
-                        static_forq<0, NOB>([&](auto b_c) { mfma1(kk_c, b_c, TC{}); });
-                    });
+                // slot m: MFMA m — order (term, tap, block): consecutive MFMAs go to different accumulators (the three terms of
+                // one block are a dependent chain) — then fillers [m NF / NM, (m+1) NF / NM)
+                static_forq<0, NM>([&](auto m_c) {
+                    constexpr int m = decltype(m_c)::value;
+                    constexpr int term = TERMS == 3 ? m / (3 * NOB) : 2, kk = (m / NOB) % 3, b = m % NOB;
+                    mfma1(std::integral_constant<int, kk>{}, std::integral_constant<int, b>{}, std::integral_constant<int, term>{});
+                    static_forq<m * NF / NM, (m + 1) * NF / NM>([&](auto f_c) { filler(f_c); });
+                    __builtin_amdgcn_sched_barrier(0);
                 });
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (s < 8) chunk(s_c);               // staging between the MFMA groups
-                __builtin_amdgcn_sched_barrier(0);
             });
         }
         __syncthreads();                          // unit g+1 is staged; tile g & 1 and the ring slots behind the window are free

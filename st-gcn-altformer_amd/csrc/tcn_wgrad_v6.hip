@@ -11,8 +11,8 @@
 //   * a workgroup walks whole CLIPS in units of TWO output frames (3 k-steps of 16 padded pixels, 81 MFMAs per wave);
 //   * the input tile is a RING of 16 frame slots per channel row: a unit adds its two new frames (the other eight of its
 //     ten-frame window are already there); four MFMA-free lead-in units per clip fill the ring;
-//   * two dz tiles; staging of unit g+1 (convert + LDS stores) and the loads of unit g+2 sit BETWEEN the MFMA groups of
-//     unit g — there is no staging phase; one barrier per unit;
+//   * two dz tiles; staging of unit g+1 (convert + LDS stores) and the loads of unit g+2 are cut into pieces of a few
+//     instructions that sit in the slots BEHIND the MFMAs of unit g — there is no staging phase; one barrier per unit;
 //   * fragment reads of the next tap group are issued before the current group's MFMAs.
 // Partial sums per workgroup, summed in a fixed order by sum_partials_kernel as before.
 #include <type_traits>

@@ -672,7 +672,13 @@ def _kink_free_cotangent(y_ref, gen):
     (64, 64, 9, 1, 3, 40, 22, True),       # TCN_GCN_unit(64, 64): 64 output channels on the 128-channel matrix-core tiles
     (64, 128, 1, 1, 2, 12, 25, True),      # 1x1 (the residual "down" convs of the deeper layers)
     (128, 128, 4, 1, 2, 11, 22, True),     # EVEN K: the forward drops a frame (Tout = T-1); dgrad must not be the
-    (32, 64, 2, 1, 2, 7, 22, True)])       #   flipped-weight forward there, wgrad not the Tout==T kernel
+    (32, 64, 2, 1, 2, 7, 22, True),        #   flipped-weight forward there, wgrad not the Tout==T kernel
+    # corners of the one-wave-per-SIMD wgrad (tcn_wgrad_v6.hip: 17 <= V <= 24, odd K, ring of frames, two-frame units):
+    (128, 256, 9, 1, 3, 13, 17, True),     # V = 17 (7 padded columns a frame: dz is not masked there, the input is), odd T, 2 row groups
+    (96, 128, 7, 1, 5, 8, 24, False),      # V = 24 (no padding), three 32-channel groups (one block per wave), K = 7, clips % splits != 0
+    (64, 128, 3, 1, 2, 5, 20, True),       # K = 3, clip shorter than the ring's window
+    (128, 64, 1, 1, 2, 6, 19, True),       # K = 1, 64 output channels (half the dz tile reads as zeros)
+    (64, 128, 9, 1, 1, 1, 22, True)])      # one clip of ONE frame: lead-in units only + a half-empty unit
 def test_unit2d_backward_vs_oracle(cin, cout, K, stride, N, T, V, bias, math, dev):
     from stgcn_amd import Unit2D, set_math_mode
     from oracle import stgcn_oracle as so

@@ -51,8 +51,19 @@ __device__ __forceinline__ void static_forq(F &&f) {
 template <int TERMS, int NOB>
 __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *__restrict__ dz, const float *__restrict__ x,
                                                                    float *__restrict__ part, int N, int Cin, int Cout, int T,
-                                                                   int V, int K, int cpw /* clips per workgroup */) {
-    // (no run-time ablation switches in here: inside the unrolled MFMA groups they tripled the kernel's time)
+                                                                   int V, int K, int cpw /* clips per workgroup */,
+                                                                   unsigned long long *dbg, int dbg_mode) {
+    // (no run-time ablation switches in here: inside the unrolled MFMA groups they tripled the kernel's time; diagnostic
+    //  builds can stamp the clock at group boundaries: tools/stamps_wgrad.py)
+#ifdef STGCN_ABLATION
+#define WQ_STAMP(var) unsigned long long var = 0; if (dbg) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); }
+#define WQ_ACC(slot, a, b) if (dbg) { tsum[slot] += (b) - (a); }
+    unsigned long long tsum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int stamp_groups = dbg ? dbg_mode : 0;   // 1: also stamp every MFMA group (drains the LDS queue: perturbs)
+#else
+#define WQ_STAMP(var)
+#define WQ_ACC(slot, a, b)
+#endif
     extern __shared__ __attribute__((aligned(16))) char smq[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,45 +216,51 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
     __syncthreads();
 
     for (int g = 0; g < nun; ++g) {
+        WQ_STAMP(t_u0)
         const bool l2 = g + 2 < nun;              // the unit whose loads are issued during this one (all scalar)
         const int n2 = __builtin_amdgcn_readfirstlane(l2 ? unit_clip(g + 2) : clip0), t2 = __builtin_amdgcn_readfirstlane(l2 ? unit_t0(g + 2) : -1);
         char *acur = smq + (g & 1) * ATILE, *anxt = smq + ((g + 1) & 1) * ATILE;
         // Staging of unit g+1 (convert + LDS stores) and the loads of unit g+2, cut into PIECES of a few instructions that go
         // into the slots after the MFMAs (an MFMA occupies the pipe for 32 cycles; instructions placed right behind it issue
         // meanwhile — clumped between the groups they left the pipe idle for a quarter of the unit).  Piece list, in order:
-        //   per dz register set i = 0..2 (9 pieces): pack pair 0..3 | write hi | write lo | offset | load 0..3 | load 4..7
-        //   per input set q (6 pieces):              pack pair 0..3 (columns >= V zeroed) | write hi | write lo
-        //   per input set q (3 pieces):              offset | load 0..3 | load 4..7
+        //   per dz register set i = 0..2 (13 pieces): pack pair 0..3 (hi, lo) | write hi | write lo | offset | load 0..3 | load 4..7
+        //   per input set q (10 pieces):              pack pair 0..3 (hi with columns >= V zeroed, lo) | write hi | write lo
+        //   per input set q (3 pieces):               offset | load 0..3 | load 4..7
         unsigned sh[4], sl[4], goff = OOB;
         const __amdgpu_buffer_rsrc_t ra2 = a_rsrc(n2), rb2 = b_rsrc(n2);
-        constexpr int NP = 27 + 9 * CB;
-        auto pack_pair = [&](const float *v, int pr, int nv) {
-            const float v0 = (2 * pr < nv) ? v[2 * pr] : 0.f, v1 = (2 * pr + 1 < nv) ? v[2 * pr + 1] : 0.f;
-            sh[pr] = pack_bf16x2(v0, v1);
-            if constexpr (TERMS == 3) sl[pr] = pack_bf16x2(v0 - bf16_lo_to_f32(sh[pr]), v1 - bf16_hi_to_f32(sh[pr]));
+        constexpr int PA_N = 13, PB_N = 10;       // pieces per dz set / per input set (without its 3 load pieces)
+        constexpr int NP = 3 * PA_N + (PB_N + 3) * CB;
+        // a pack is two pieces (an MFMA covers 32 cycles = eight VALU issues; a whole pair was ten instructions)
+        auto pack_hi = [&](float *v, int pr, int nv) __attribute__((always_inline)) {
+            v[2 * pr] = (2 * pr < nv) ? v[2 * pr] : 0.f;
+            v[2 * pr + 1] = (2 * pr + 1 < nv) ? v[2 * pr + 1] : 0.f;
+            sh[pr] = pack_bf16x2(v[2 * pr], v[2 * pr + 1]);
+        };
+        auto pack_lo = [&](const float *v, int pr) __attribute__((always_inline)) {
+            if constexpr (TERMS == 3) sl[pr] = pack_bf16x2(v[2 * pr] - bf16_lo_to_f32(sh[pr]), v[2 * pr + 1] - bf16_hi_to_f32(sh[pr]));
         };
         auto piece = [&](auto p_c) __attribute__((always_inline)) {
             constexpr int P = decltype(p_c)::value;
-            if constexpr (P < 27) {
-                constexpr int i = P / 9, r = P % 9;
-                if constexpr (r < 4) pack_pair(pa[i], r, 8);
-                else if constexpr (r == 4) *reinterpret_cast<uint4 *>(anxt + a_lds[i]) = make_uint4(sh[0], sh[1], sh[2], sh[3]);
-                else if constexpr (r == 5) { if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(anxt + AIMG + a_lds[i]) = make_uint4(sl[0], sl[1], sl[2], sl[3]); }
-                else if constexpr (r == 6) goff = a_off(i, l2, t2);
-                else if constexpr (r == 7) load4(&pa[i][0], ra2, goff);
+            if constexpr (P < 3 * PA_N) {
+                constexpr int i = P / PA_N, r = P % PA_N;
+                if constexpr (r < 8) { if constexpr (r % 2 == 0) pack_hi(pa[i], r / 2, 8); else pack_lo(pa[i], r / 2); }
+                else if constexpr (r == 8) *reinterpret_cast<uint4 *>(anxt + a_lds[i]) = make_uint4(sh[0], sh[1], sh[2], sh[3]);
+                else if constexpr (r == 9) { if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(anxt + AIMG + a_lds[i]) = make_uint4(sl[0], sl[1], sl[2], sl[3]); }
+                else if constexpr (r == 10) goff = a_off(i, l2, t2);
+                else if constexpr (r == 11) load4(&pa[i][0], ra2, goff);
                 else load4(&pa[i][4], ra2, goff + 16);
-            } else if constexpr (P < 27 + 6 * CB) {
-                constexpr int q = (P - 27) / 6, r = (P - 27) % 6;
-                if constexpr (r < 4) pack_pair(pb[q], r, b_nv[q]);
+            } else if constexpr (P < 3 * PA_N + PB_N * CB) {
+                constexpr int q = (P - 3 * PA_N) / PB_N, r = (P - 3 * PA_N) % PB_N;
+                if constexpr (r < 8) { if constexpr (r % 2 == 0) pack_hi(pb[q], r / 2, b_nv[q]); else pack_lo(pb[q], r / 2); }
                 else {
                     // ring slots of unit g+1's new frames (past the last unit they take zeros nobody reads)
                     const int slot = (2 * (g + 1) + (WQ_WIN - WQ_TFM) + b_ff[q]) & (WQ_RING - 1);
                     char *dp = Bring + b_row[q] * WQ_PITCH_B + slot * WQ_FRB + b_uq[q] * 16;
-                    if constexpr (r == 4) { if (b_live[q]) *reinterpret_cast<uint4 *>(dp) = make_uint4(sh[0], sh[1], sh[2], sh[3]); }
+                    if constexpr (r == 8) { if (b_live[q]) *reinterpret_cast<uint4 *>(dp) = make_uint4(sh[0], sh[1], sh[2], sh[3]); }
                     else if constexpr (TERMS == 3) { if (b_live[q]) *reinterpret_cast<uint4 *>(dp + BIMG) = make_uint4(sl[0], sl[1], sl[2], sl[3]); }
                 }
             } else {
-                constexpr int q = (P - 27 - 6 * CB) / 3, r = (P - 27 - 6 * CB) % 3;
+                constexpr int q = (P - 3 * PA_N - PB_N * CB) / 3, r = (P - 3 * PA_N - PB_N * CB) % 3;
                 if constexpr (r == 0) goff = b_off(q, l2, t2);
                 else if constexpr (r == 1) load4(&pb[q][0], rb2, goff);
                 else load4(&pb[q][4], rb2, goff + 16);
@@ -283,6 +300,10 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
             }
             static_forq<0, 9>([&](auto s_c) {                   // 9 MFMA groups: (k-step, tap group)
                 constexpr int s = decltype(s_c)::value, ks = s / 3, grp = s % 3, set = s & 1;
+#ifdef STGCN_ABLATION
+                unsigned long long t_g0 = 0;
+                if (stamp_groups) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_g0) :: "memory");
+#endif
                 // fillers of this group: the next group's input fragments (6 reads), the next k-step's dz fragments (2 per
                 // block, at the k-step's first group), then this group's share of the staging pieces
                 constexpr int NRB = s + 1 < 9 ? 3 * (TERMS == 3 ? 2 : 1) : 0;
@@ -292,6 +313,12 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
                 constexpr int NM = (TERMS == 3 ? 3 : 1) * 3 * NOB;
                 auto filler = [&](auto f_c) __attribute__((always_inline)) {
                     constexpr int f = decltype(f_c)::value;
+#if defined(STGCN_ABLATION) && defined(WQ_NOREADS)       // diagnostic variants (results wrong): price the fillers
+                    if constexpr (f < NRB + NRA) return;
+#endif
+#if defined(STGCN_ABLATION) && defined(WQ_NOPIECES)
+                    if constexpr (f >= NRB + NRA) return;
+#endif
                     if constexpr (f < NRB) {
                         constexpr int kk = f % 3, lo = f / 3, s1 = s + 1;
                         const char *p = b_addr(std::integral_constant<int, s1 / 3>{}, std::integral_constant<int, (s1 % 3) * 3 + kk>{});
@@ -333,10 +360,25 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
                     static_forq<m * NF / NM, (m + 1) * NF / NM>([&](auto f_c) { filler(f_c); });
                     __builtin_amdgcn_sched_barrier(0);
                 });
+#ifdef STGCN_ABLATION
+                if (stamp_groups) {
+                    unsigned long long t_g1;
+                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_g1) :: "memory");
+                    tsum[s] += t_g1 - t_g0;
+                }
+#endif
             });
         }
+        WQ_STAMP(t_u1)
         __syncthreads();                          // unit g+1 is staged; tile g & 1 and the ring slots behind the window are free
+        WQ_STAMP(t_u2)
+        WQ_ACC(9, t_u0, t_u1)                     // the unit's work
+        WQ_ACC(10, t_u1, t_u2)                    // barrier wait
     }
+#ifdef STGCN_ABLATION
+    if (dbg && lane == 0 && zi < 8 && cg == 0 && blockIdx.y == 0)
+        for (int i = 0; i < 12; ++i) dbg[(zi * 4 + wave) * 12 + i] = tsum[i];
+#endif
 
     // D[row = o][col = c]: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float *dst = part + (size_t)zi * Cout * Cin * K;
@@ -390,7 +432,7 @@ int launch_tcn_wgrad_v6(const float *dz, const float *x, float *part, int N, int
     do {                                                                                                              \
         STGCN_HIP_CHECK(allow_lds((tcn_wgrad_v6_kernel<TERMS, NOB>), lds));                                           \
         hipLaunchKernelGGL((tcn_wgrad_v6_kernel<TERMS, NOB>), grid, dim3(WQ_THREADS), lds, st, dz, x, part, N, Cin, Cout, T, V, K, \
-                           cpw);                                                                                                    \
+                           cpw, debug_buffer(), (ablate_mask() & 64) ? 1 : 0);                                                                                                    \
     } while (0)
     if (math == STGCN_MATH_BF16X3) { if (two) LAUNCH_WQ(3, 2); else LAUNCH_WQ(3, 1); }
     else { if (two) LAUNCH_WQ(1, 2); else LAUNCH_WQ(1, 1); }

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
         //   per dz register set i = 0..2 (13 pieces): pack pair 0..3 (hi, lo) | write hi | write lo | offset | load 0..3 | load 4..7
         //   per input set q (10 pieces):              pack pair 0..3 (hi with columns >= V zeroed, lo) | write hi | write lo
         //   per input set q (3 pieces):               offset | load 0..3 | load 4..7
-        unsigned sh[4], sl[4], goff = OOB;
+        unsigned sh[4] = {0, 0, 0, 0}, sl[4] = {0, 0, 0, 0}, goff = OOB;
         const __amdgpu_buffer_rsrc_t ra2 = a_rsrc(n2), rb2 = b_rsrc(n2);
         constexpr int PA_N = 13, PB_N = 10;       // pieces per dz set / per input set (without its 3 load pieces)
         constexpr int NP = 3 * PA_N + (PB_N + 3) * CB;
@@ -241,6 +241,21 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
         };
         auto piece = [&](auto p_c) __attribute__((always_inline)) {
             constexpr int P = decltype(p_c)::value;
+#if defined(STGCN_ABLATION) && (defined(WQ_NOPACK) || defined(WQ_NOWRITE) || defined(WQ_NOLOADS))
+            {   // diagnostic variants (results wrong): price one kind of piece
+                constexpr bool isA = P < 3 * PA_N, isB = !isA && P < 3 * PA_N + PB_N * CB;
+                constexpr int rr = isA ? P % PA_N : (isB ? (P - 3 * PA_N) % PB_N : 11);
+#ifdef WQ_NOPACK
+                if constexpr (rr < 8) return;
+#endif
+#ifdef WQ_NOWRITE
+                if constexpr (rr == 8 || rr == 9) return;
+#endif
+#ifdef WQ_NOLOADS
+                if constexpr (rr >= 10) return;
+#endif
+            }
+#endif
             if constexpr (P < 3 * PA_N) {
                 constexpr int i = P / PA_N, r = P % PA_N;
                 if constexpr (r < 8) { if constexpr (r % 2 == 0) pack_hi(pa[i], r / 2, 8); else pack_lo(pa[i], r / 2); }

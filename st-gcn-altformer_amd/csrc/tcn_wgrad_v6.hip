@@ -215,10 +215,21 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
     }
     __syncthreads();
 
+    // the first group's input fragments of a unit are read during the last group of the unit before (frames 0 .. 2 of a window
+    // were staged three units earlier: no barrier between them and these reads is needed)
+    uint4 b0h[3], b0l[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+        b0h[kk] = *reinterpret_cast<const uint4 *>(Bring + b_lane[0] + kk * WQ_FRB);
+        b0l[kk] = b0h[kk];
+        if constexpr (TERMS == 3) b0l[kk] = *reinterpret_cast<const uint4 *>(Bring + BIMG + b_lane[0] + kk * WQ_FRB);
+    }
+    int u2 = 2, c2 = clip0;                       // unit g+2: index within its clip (upc >= 5) and clip — carried, not divided
     for (int g = 0; g < nun; ++g) {
         WQ_STAMP(t_u0)
         const bool l2 = g + 2 < nun;              // the unit whose loads are issued during this one (all scalar)
-        const int n2 = __builtin_amdgcn_readfirstlane(l2 ? unit_clip(g + 2) : clip0), t2 = __builtin_amdgcn_readfirstlane(l2 ? unit_t0(g + 2) : -1);
+        // (readfirstlane: hipcc does not see that the carried counters are uniform — without it every load is a waterfall loop)
+        const int n2 = __builtin_amdgcn_readfirstlane(l2 ? c2 : clip0), t2 = __builtin_amdgcn_readfirstlane(l2 ? (u2 - WQ_LEAD) * WQ_TFM : -1);
         char *acur = smq + (g & 1) * ATILE, *anxt = smq + ((g + 1) & 1) * ATILE;
         // Staging of unit g+1 (convert + LDS stores) and the loads of unit g+2, cut into PIECES of a few instructions that go
         // into the slots after the MFMAs (an MFMA occupies the pipe for 32 cycles; instructions placed right behind it issue
@@ -295,17 +306,6 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
                 return Bring + b_lane[ks] + sel;
             };
             uint4 bh[2][3], bl[2][3];
-            auto read_group = [&](auto ks_c, auto grp_c, auto set_c) {
-                constexpr int grp = decltype(grp_c)::value, set = decltype(set_c)::value;
-                static_forq<0, 3>([&](auto kk_c) {
-                    constexpr int kk = decltype(kk_c)::value;
-                    const char *p = b_addr(ks_c, std::integral_constant<int, grp * 3 + kk>{});
-                    bh[set][kk] = *reinterpret_cast<const uint4 *>(p);
-                    if constexpr (TERMS == 3) bl[set][kk] = *reinterpret_cast<const uint4 *>(p + BIMG);
-                });
-            };
-            using I0 = std::integral_constant<int, 0>;
-            read_group(I0{}, I0{}, I0{});
             uint4 ahs[2][NOB], als[2][NOB];       // dz fragments of a k-step, read one k-step ahead
 #pragma unroll
             for (int b = 0; b < NOB; ++b) {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
 #endif
                 // fillers of this group: the next group's input fragments (6 reads), the next k-step's dz fragments (2 per
                 // block, at the k-step's first group), then this group's share of the staging pieces
-                constexpr int NRB = s + 1 < 9 ? 3 * (TERMS == 3 ? 2 : 1) : 0;
+                constexpr int NRB = 3 * (TERMS == 3 ? 2 : 1);       // (group 8: the NEXT unit's group 0)
                 constexpr int NRA = (grp == 0 && ks + 1 < 3) ? NOB * (TERMS == 3 ? 2 : 1) : 0;
                 constexpr int P0 = s * NP / 9, P1 = (s + 1) * NP / 9;
                 constexpr int NF = NRB + NRA + (P1 - P0);
@@ -336,9 +336,17 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
 #endif
                     if constexpr (f < NRB) {
                         constexpr int kk = f % 3, lo = f / 3, s1 = s + 1;
-                        const char *p = b_addr(std::integral_constant<int, s1 / 3>{}, std::integral_constant<int, (s1 % 3) * 3 + kk>{});
-                        if constexpr (lo == 0) bh[s1 & 1][kk] = *reinterpret_cast<const uint4 *>(p);
-                        else bl[s1 & 1][kk] = *reinterpret_cast<const uint4 *>(p + BIMG);
+                        if constexpr (s1 == 9) {              // next unit: its window frame kk is this unit's frame kk + 2
+                            const char *p = Bring + b_lane[0] + so[kk + 2];
+                            if constexpr (lo == 0) {
+                                b0h[kk] = *reinterpret_cast<const uint4 *>(p);
+                                if constexpr (TERMS != 3) b0l[kk] = b0h[kk];
+                            } else b0l[kk] = *reinterpret_cast<const uint4 *>(p + BIMG);
+                        } else {
+                            const char *p = b_addr(std::integral_constant<int, s1 / 3>{}, std::integral_constant<int, (s1 % 3) * 3 + kk>{});
+                            if constexpr (lo == 0) bh[s1 & 1][kk] = *reinterpret_cast<const uint4 *>(p);
+                            else bl[s1 & 1][kk] = *reinterpret_cast<const uint4 *>(p + BIMG);
+                        }
                     } else if constexpr (f < NRB + NRA) {
                         constexpr int b = (f - NRB) % NOB, lo = (f - NRB) / NOB, k1 = ks + 1;
                         const char *p = acur + a_lane + b * 32 * WQ_PITCH_A + k1 * 32;
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
                 auto mfma1 = [&](auto kk_c, auto b_c, auto term_c) __attribute__((always_inline)) {
                     constexpr int kk = decltype(kk_c)::value, b = decltype(b_c)::value, term = decltype(term_c)::value, tap = grp * 3 + kk;
                     const uint4 av = term == 1 ? als[ks & 1][b] : ahs[ks & 1][b];
-                    const uint4 bv = term == 0 ? bl[set][kk] : bh[set][kk];
+                    const uint4 bv = s == 0 ? (term == 0 ? b0l[kk] : b0h[kk]) : (term == 0 ? bl[set][kk] : bh[set][kk]);
                     if constexpr (NOB == 2 && tap == 8) {
                         // 2 x 9 accumulators are 288 registers, 32 more than the AGPR file: through the builtin hipcc rotated
                         // blocks between the two files (850 copies per unit).  The last tap's accumulators live in VGPRs,
@@ -386,6 +394,7 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
         }
         WQ_STAMP(t_u1)
         __syncthreads();                          // unit g+1 is staged; tile g & 1 and the ring slots behind the window are free
+        if (++u2 == upc) { u2 = 0; ++c2; }
         WQ_STAMP(t_u2)
         WQ_ACC(9, t_u0, t_u1)                     // the unit's work
         WQ_ACC(10, t_u1, t_u2)                    // barrier wait

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STGCN_ABI_VERSION 6
+#define STGCN_ABI_VERSION 7
 
 typedef enum {
     STGCN_OK = 0,
@@ -64,6 +64,11 @@ typedef enum {
 #define STGCN_OUT_NTVC 0x80u
 /* stgcn_patch_embed: rows ordered (clip, joint, frame) — model_TS.py:161 — instead of (clip, frame, joint) */
 #define STGCN_EMBED_TS 0x100u
+/* stgcn_*_forward_train / stgcn_*_backward_train: BatchNorm on its RUNNING statistics (module.eval() with autograd — frozen-
+ * BatchNorm fine-tuning, saliency; the reference's nn.BatchNorm2d stays differentiable in eval mode, model/net.py:52,
+ * model/unit_agcn.py:54,91).  Forward: normalises with running_mean / running_var, leaves both untouched, and saves them as
+ * (mean, invstd).  Backward: mean and invstd are constants — dz = gamma*invstd*g, dgamma = sum g*xhat, dbeta = sum g. */
+#define STGCN_BN_FROZEN 0x200u
 
 int stgcn_version(void);
 const char *stgcn_last_error(void);
@@ -182,7 +187,7 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
                              float *dbn_running_var, float momentum, float eps, float *P_ws, void *ws,
                              size_t ws_bytes, float *y, float *save_zm, float *save_zd, float *save_stats,
                              int N, int Cin, int Cout, int T, int V, int inter_c, int subsets,
-                             void *stream);
+                             unsigned flags /* 0 or STGCN_BN_FROZEN (then size ws with materialise = 1) */, void *stream);
 /* save_zm / save_zd (N,Cout,T,V): the two pre-BatchNorm branches (sum_s conv_d_s(x P_s), conv_down(x)) — asking for
  * them selects the materialising path; save_stats (STGCN_AGCN_SAVE_STATS_FLOATS(Cout) floats, 8-byte aligned): batch
  * mean, invstd of `bn`, then of the down BatchNorm (4*Cout), followed — on the moments path only — by the 63 feature
@@ -212,7 +217,8 @@ int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *W
                               const float *y, const float *dy, float *dWa, float *dba, float *dWb, float *dbb, float *dWd,
                               float *dbd, float *dWdown, float *dbdown, float *dgamma, float *dbeta,
                               float *ddgamma, float *ddbeta, float *dPA, float *dx, void *ws, size_t ws_bytes,
-                              int N, int Cin, int Cout, int T, int V, int inter_c, int subsets, void *stream);
+                              int N, int Cin, int Cout, int T, int V, int inter_c, int subsets,
+                              unsigned flags /* 0 or STGCN_BN_FROZEN (generic path: size ws with recompute bit 1) */, void *stream);
 size_t stgcn_tcn_train_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
 /* save_z (N,Cout,T_out,V), save_mean, save_invstd (Cout): optional outputs for the backward — the raw
  * convolution conv_t(x)+b and the batch statistics, torch's save_mean / save_invstd.  NULL: not kept. */

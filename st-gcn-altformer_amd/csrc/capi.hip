@@ -305,7 +305,7 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
                              float *bn_running_var, const float *dbn_weight, const float *dbn_bias,
                              float *dbn_running_mean, float *dbn_running_var, float momentum, float eps, float *P_ws,
                              void *ws, size_t ws_bytes, float *y, float *save_zm, float *save_zd, float *save_stats,
-                             int N, int Cin, int Cout, int T, int V, int inter_c, int subsets, void *stream) {
+                             int N, int Cin, int Cout, int T, int V, int inter_c, int subsets, unsigned flags, void *stream) {
     REQUIRE_PTR(Wd); REQUIRE_PTR(bd); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias); REQUIRE_PTR(bn_running_mean);
     REQUIRE_PTR(bn_running_var); REQUIRE_PTR(ws); REQUIRE_PTR(y); REQUIRE_POS(Cout);
     const bool has_down = Wdown != nullptr;
@@ -315,7 +315,8 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
         return fail(STGCN_ERR_ARG, "agcn_forward_train: identity residual needs Cin == Cout (got %d, %d)", Cin, Cout);
     int rc = stgcn_agcn_attention(x, A_eff, Wa, ba, Wb, bb, P_ws, N, Cin, T, V, inter_c, subsets, stream);
     if (rc != STGCN_OK) return rc;
-    const bool moments = has_down && !save_zm && !save_zd && agcn_moments_supported(Cin, V, subsets);
+    const bool frozen = (flags & STGCN_BN_FROZEN) != 0;     // running statistics: the branches are materialised
+    const bool moments = !frozen && has_down && !save_zm && !save_zd && agcn_moments_supported(Cin, V, subsets);
     if (ws_bytes < stgcn_agcn_train_ws_bytes(N, Cin, Cout, T, V, subsets, moments ? 0 : 1))
         return fail(STGCN_ERR_WORKSPACE, "agcn_forward_train: workspace %zu B too small", ws_bytes);
     hipStream_t st = (hipStream_t)stream;
@@ -341,19 +342,28 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
     rc = launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, ones, zeros, has_down ? zeros : nullptr,
                             has_down ? zeros : nullptr, zm, N, Cin, Cout, T, V, subsets, 1 | 2, st);
     if (rc != STGCN_OK) return rc;
-    rc = launch_bn_batch_stats(zm, sums1, N, Cout, plane, st);
-    if (rc != STGCN_OK) return rc;
-    rc = launch_bn_train_finalize(sums1, (double)N * plane, bn_weight, bn_bias, bn_running_mean, bn_running_var, momentum,
-                                  eps, s1, t1, Cout, st, sv_mm, sv_im);
+    if (frozen) {
+        rc = launch_bn_frozen_finalize(bn_weight, bn_bias, bn_running_mean, bn_running_var, eps, s1, t1, Cout, st, sv_mm, sv_im);
+    } else {
+        rc = launch_bn_batch_stats(zm, sums1, N, Cout, plane, st);
+        if (rc != STGCN_OK) return rc;
+        rc = launch_bn_train_finalize(sums1, (double)N * plane, bn_weight, bn_bias, bn_running_mean, bn_running_var, momentum,
+                                      eps, s1, t1, Cout, st, sv_mm, sv_im);
+    }
     if (rc != STGCN_OK) return rc;
     if (has_down) {  // residual branch, pre-BN: conv_down(x)
         rc = launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, zeros, zeros, ones, zeros, zd, N, Cin, Cout, T, V, subsets,
                                 1, st);
         if (rc != STGCN_OK) return rc;
-        rc = launch_bn_batch_stats(zd, sums2, N, Cout, plane, st);
-        if (rc != STGCN_OK) return rc;
-        rc = launch_bn_train_finalize(sums2, (double)N * plane, dbn_weight, dbn_bias, dbn_running_mean, dbn_running_var,
-                                      momentum, eps, s2, t2, Cout, st, sv_md, sv_id);
+        if (frozen) {
+            rc = launch_bn_frozen_finalize(dbn_weight, dbn_bias, dbn_running_mean, dbn_running_var, eps, s2, t2, Cout, st, sv_md,
+                                           sv_id);
+        } else {
+            rc = launch_bn_batch_stats(zd, sums2, N, Cout, plane, st);
+            if (rc != STGCN_OK) return rc;
+            rc = launch_bn_train_finalize(sums2, (double)N * plane, dbn_weight, dbn_bias, dbn_running_mean, dbn_running_var,
+                                          momentum, eps, s2, t2, Cout, st, sv_md, sv_id);
+        }
         if (rc != STGCN_OK) return rc;
         return launch_bn_apply(zm, s1, t1, zd, s2, t2, y, total, Cout, plane, st);
     }
@@ -408,7 +418,7 @@ int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *W
                               float *dbb,
                               float *dWd, float *dbd, float *dWdown, float *dbdown, float *dgamma, float *dbeta,
                               float *ddgamma, float *ddbeta, float *dPA, float *dx, void *ws, size_t ws_bytes, int N, int Cin,
-                              int Cout, int T, int V, int inter_c, int subsets, void *stream) {
+                              int Cout, int T, int V, int inter_c, int subsets, unsigned flags, void *stream) {
     REQUIRE_PTR(x); REQUIRE_PTR(A_eff); REQUIRE_PTR(Wa); REQUIRE_PTR(ba); REQUIRE_PTR(Wb); REQUIRE_PTR(bb); REQUIRE_PTR(Wd);
     REQUIRE_PTR(bd); REQUIRE_PTR(P); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias);
     REQUIRE_PTR(save_stats); REQUIRE_PTR(dy); REQUIRE_PTR(dWa); REQUIRE_PTR(dba);
@@ -425,7 +435,10 @@ int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *W
     if (V > 64) return fail(STGCN_ERR_UNSUPPORTED, "agcn_backward: V=%d > 64", V);
     if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "agcn_backward: N=%d > 65535 clips per call", N);
     // the stem-class moment form wants what a moments-path forward leaves: no saved branches, the output y, the moments
-    const bool fused = agcn_bwd_use_fused(N, Cin, Cout, T, V, subsets, has_down, dx != nullptr, zm == nullptr && y != nullptr);
+    // the stem-class moment form is the closed form of the BATCH-statistics BatchNorm: frozen statistics take the GEMM chain
+    const bool frozen = (flags & STGCN_BN_FROZEN) != 0;
+    const bool fused = !frozen &&
+                       agcn_bwd_use_fused(N, Cin, Cout, T, V, subsets, has_down, dx != nullptr, zm == nullptr && y != nullptr);
     if (inter_c > (Cout / 4 > 0 ? Cout / 4 : 1) && !fused)
         return fail(STGCN_ERR_UNSUPPORTED, "agcn_backward: inter_c=%d > Cout/4 (workspace is sized for coff_embedding >= 4)", inter_c);
     if (has_down ? ((zm == nullptr) != (zd == nullptr)) : (zd != nullptr))
@@ -472,10 +485,10 @@ int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *W
     const float *mb = has_down ? mean_d : nullptr, *ib = has_down ? inv_d : nullptr;
     rc = launch_bn_relu_bwd_stats(zm, sm_, tm_, mean_m, inv_m, zb, sb, tb, mb, ib, dy, sums, N, Cout, plane, st);
     if (rc != STGCN_OK) return rc;
-    rc = launch_bn_bwd_finalize(sums, 1, (double)N * plane, bn_weight, inv_m, dgamma, dbeta, coefm, Cout, st);
+    rc = launch_bn_bwd_finalize(sums, 1, (double)N * plane, bn_weight, inv_m, dgamma, dbeta, coefm, Cout, st, frozen);
     if (rc != STGCN_OK) return rc;
     if (has_down) {
-        rc = launch_bn_bwd_finalize(sums, 2, (double)N * plane, dbn_weight, inv_d, ddgamma, ddbeta, coefd, Cout, st);
+        rc = launch_bn_bwd_finalize(sums, 2, (double)N * plane, dbn_weight, inv_d, ddgamma, ddbeta, coefd, Cout, st, frozen);
         if (rc != STGCN_OK) return rc;
     }
     // generic path: materialise both pre-BatchNorm gradients, then the GEMM chain
@@ -496,6 +509,7 @@ int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *W
 
 // workspace layout (tcn): [ones C][zeros C][scale, shift][sums 2C doubles][packed weights][z N*Cout*Tout*V]
 size_t stgcn_tcn_train_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags) {
+    flags &= ~STGCN_BN_FROZEN;
     if (N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || K <= 0 || stride <= 0) return 0;
     const int Tout = (T + 2 * ((K - 1) / 2) - K) / stride + 1;
     if (Tout < 1) return 0;
@@ -507,6 +521,8 @@ int stgcn_tcn_forward_train(const float *x, const float *W, const float *conv_bi
                             float eps, void *ws, size_t ws_bytes, float *y, float *save_z, float *save_mean,
                             float *save_invstd, int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags,
                             void *stream) {
+    const bool frozen = (flags & STGCN_BN_FROZEN) != 0;
+    flags &= ~STGCN_BN_FROZEN;
     REQUIRE_PTR(x); REQUIRE_PTR(W); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias); REQUIRE_PTR(bn_running_mean);
     REQUIRE_PTR(bn_running_var); REQUIRE_PTR(ws); REQUIRE_PTR(y);
     REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(Cout); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(K); REQUIRE_POS(stride);
@@ -528,10 +544,15 @@ int stgcn_tcn_forward_train(const float *x, const float *W, const float *conv_bi
     rc = launch_tcn(x, packed, conv_bias ? conv_bias : zeros, z, N, Cin, Cout, T, V, K, stride,
                     (flags & STGCN_MATH_MASK) | STGCN_RAW, st);
     if (rc != STGCN_OK) return rc;
-    rc = launch_bn_batch_stats(z, sums, N, Cout, plane, st);
-    if (rc != STGCN_OK) return rc;
-    rc = launch_bn_train_finalize(sums, (double)N * plane, bn_weight, bn_bias, bn_running_mean, bn_running_var, momentum,
-                                  eps, s1, t1, Cout, st, save_mean, save_invstd);
+    if (frozen) {
+        rc = launch_bn_frozen_finalize(bn_weight, bn_bias, bn_running_mean, bn_running_var, eps, s1, t1, Cout, st, save_mean,
+                                       save_invstd);
+    } else {
+        rc = launch_bn_batch_stats(z, sums, N, Cout, plane, st);
+        if (rc != STGCN_OK) return rc;
+        rc = launch_bn_train_finalize(sums, (double)N * plane, bn_weight, bn_bias, bn_running_mean, bn_running_var, momentum,
+                                      eps, s1, t1, Cout, st, save_mean, save_invstd);
+    }
     if (rc != STGCN_OK) return rc;
     return launch_bn_apply(z, s1, t1, nullptr, nullptr, nullptr, y, total, Cout, plane, st);
 }
@@ -553,6 +574,7 @@ static unsigned tcn_dgrad_flags(int Cin, int Cout, int Tout, int V, int K, unsig
 static bool tcn_dgrad_by_forward(int K, int stride) { return stride == 1 && (K & 1) == 1; }
 
 size_t stgcn_tcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags) {
+    flags &= ~STGCN_BN_FROZEN;
     if (N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || K <= 0 || stride <= 0) return 0;
     const int Tout = (T + 2 * ((K - 1) / 2) - K) / stride + 1;
     if (Tout < 1) return 0;
@@ -567,6 +589,8 @@ int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, con
                              const float *bn_bias, const float *save_mean, const float *save_invstd, const float *dy,
                              float *dx, float *dW, float *dbias, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
                              int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags, void *stream) {
+    const bool frozen = (flags & STGCN_BN_FROZEN) != 0;
+    flags &= ~STGCN_BN_FROZEN;
     REQUIRE_PTR(x); REQUIRE_PTR(W); REQUIRE_PTR(z); REQUIRE_PTR(bn_weight); REQUIRE_PTR(bn_bias); REQUIRE_PTR(save_mean);
     REQUIRE_PTR(save_invstd); REQUIRE_PTR(dy); REQUIRE_PTR(dW); REQUIRE_PTR(dgamma); REQUIRE_PTR(dbeta); REQUIRE_PTR(ws);
     REQUIRE_POS(N); REQUIRE_POS(Cin); REQUIRE_POS(Cout); REQUIRE_POS(T); REQUIRE_POS(V); REQUIRE_POS(K); REQUIRE_POS(stride);
@@ -588,7 +612,7 @@ int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, con
     rc = launch_bn_relu_bwd_stats(z, scale, shift, save_mean, save_invstd, nullptr, nullptr, nullptr, nullptr, nullptr, dy,
                                   sums, N, Cout, plane, st);
     if (rc != STGCN_OK) return rc;
-    rc = launch_bn_bwd_finalize(sums, 1, (double)N * plane, bn_weight, save_invstd, dgamma, dbeta, coef, Cout, st);
+    rc = launch_bn_bwd_finalize(sums, 1, (double)N * plane, bn_weight, save_invstd, dgamma, dbeta, coef, Cout, st, frozen);
     if (rc != STGCN_OK) return rc;
     rc = launch_bn_relu_bwd_apply(z, scale, shift, save_mean, save_invstd, nullptr, nullptr, nullptr, nullptr, nullptr, dy,
                                   coef, nullptr, dz, nullptr, dbias ? bsum : nullptr, N, Cout, plane, st);

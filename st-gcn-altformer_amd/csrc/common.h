@@ -156,6 +156,9 @@ int launch_bn_train_finalize(const double *sums, double count, const float *weig
                              float *running_mean, float *running_var, float momentum, float eps, float *scale,
                              float *shift, int C, hipStream_t st, float *save_mean = nullptr,
                              float *save_invstd = nullptr);
+int launch_bn_frozen_finalize(const float *weight, const float *bias, const float *running_mean, const float *running_var,
+                              float eps, float *scale, float *shift, int C, hipStream_t st, float *save_mean = nullptr,
+                              float *save_invstd = nullptr);
 int launch_bn_scale_shift(const float *weight, const float *bias, const float *mean, const float *invstd, float *scale,
                           float *shift, int C, hipStream_t st);
 int launch_bn_apply(const float *za, const float *sa, const float *ta, const float *zb, const float *sb,
@@ -166,7 +169,7 @@ int launch_bn_relu_bwd_stats(const float *za, const float *sa, const float *ta, 
                              const float *zb, const float *sb, const float *tb, const float *mb, const float *ib,
                              const float *dy, double *sums, int N, int C, size_t plane, hipStream_t st);
 int launch_bn_bwd_finalize(const double *sums, int which, double count, const float *gamma, const float *invstd,
-                           float *dgamma, float *dbeta, float *coef, int C, hipStream_t st);
+                           float *dgamma, float *dbeta, float *coef, int C, hipStream_t st, bool frozen = false);
 int launch_bn_relu_bwd_apply(const float *za, const float *sa, const float *ta, const float *ma, const float *ia,
                              const float *zb, const float *sb, const float *tb, const float *mb, const float *ib,
                              const float *dy, const float *coefa, const float *coefb, float *dza, float *dzb, double *bsum,

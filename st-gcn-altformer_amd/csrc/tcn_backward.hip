@@ -106,15 +106,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(BnSide a, BnSide
 __global__ void bn_bwd_finalize_kernel(const double *__restrict__ sums, int which /* 1: side a, 2: side b */, double count,
                                        const float *__restrict__ gamma, const float *__restrict__ invstd,
                                        float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef,
-                                       int C) {
+                                       int C, int frozen /* statistics are constants: no mean terms in pass 2 */) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const double sg = sums[c], sgx = sums[which * C + c];
     dgamma[c] = (float)sgx;
     dbeta[c] = (float)sg;
     coef[c] = gamma[c] * invstd[c];
-    coef[C + c] = (float)(sg / count);
-    coef[2 * C + c] = (float)(sgx / count);
+    coef[C + c] = frozen ? 0.f : (float)(sg / count);
+    coef[2 * C + c] = frozen ? 0.f : (float)(sgx / count);
 }
 
 // pass 2: dza = coefa[c] * (g - mean(g) - xhat_a*mean(g*xhat_a)), same for side b; bsum[c] += sum dza (conv bias grad),
@@ -547,9 +547,9 @@ int launch_bn_relu_bwd_stats(const float *za, const float *sa, const float *ta, 
 }
 
 int launch_bn_bwd_finalize(const double *sums, int which, double count, const float *gamma, const float *invstd,
-                           float *dgamma, float *dbeta, float *coef, int C, hipStream_t st) {
+                           float *dgamma, float *dbeta, float *coef, int C, hipStream_t st, bool frozen) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, which, count, gamma, invstd,
-                       dgamma, dbeta, coef, C);
+                       dgamma, dbeta, coef, C, frozen ? 1 : 0);
     STGCN_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     return STGCN_OK;
 }

@@ -73,6 +73,21 @@ __global__ void bn_train_finalize_kernel(const double *__restrict__ sums, double
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
 }
 
+// STGCN_BN_FROZEN: the running statistics stand in for the batch's; nothing is updated
+__global__ void bn_frozen_finalize_kernel(const float *__restrict__ weight, const float *__restrict__ bias,
+                                          const float *__restrict__ running_mean, const float *__restrict__ running_var,
+                                          float eps, float *__restrict__ scale, float *__restrict__ shift, int C,
+                                          float *__restrict__ save_mean, float *__restrict__ save_invstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float mean = running_mean[c], inv = 1.f / sqrtf(running_var[c] + eps);
+    const float s = weight[c] * inv;
+    scale[c] = s;
+    shift[c] = bias[c] - mean * s;
+    if (save_mean) save_mean[c] = mean;
+    if (save_invstd) save_invstd[c] = inv;
+}
+
 // y = relu( za*sa[c] + ta[c] + r ),  r = zb*sb[c] + tb[c]  (sb given), = zb (sb NULL, identity residual), = 0 (zb NULL)
 // grid = (chunks, C)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ za, const float *__restrict__ sa,
@@ -137,6 +152,15 @@ int launch_bn_train_finalize(const double *sums, double count, const float *weig
     hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, count, weight, bias,
                        running_mean, running_var, momentum, eps, scale, shift, C, save_mean, save_invstd);
     STGCN_LAUNCH_CHECK("bn_train_finalize_kernel");
+    return STGCN_OK;
+}
+
+int launch_bn_frozen_finalize(const float *weight, const float *bias, const float *running_mean, const float *running_var,
+                              float eps, float *scale, float *shift, int C, hipStream_t st, float *save_mean,
+                              float *save_invstd) {
+    hipLaunchKernelGGL(bn_frozen_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, weight, bias, running_mean,
+                       running_var, eps, scale, shift, C, save_mean, save_invstd);
+    STGCN_LAUNCH_CHECK("bn_frozen_finalize_kernel");
     return STGCN_OK;
 }
 

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STGCN_LIB") or os.path.join(_HERE, "libstgcn_hip.so")   # STGCN_LIB: diagnostic builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # stgcn_math / flags (include/stgcn_hip.h)
 MATH_F32 = 0
@@ -25,6 +25,7 @@ RAW = 0x20
 IN_NTVC = 0x40    # stem entry points: x is (N,T,V,Cin)
 OUT_NTVC = 0x80   # stem entry points: out is (N,T,V,C)
 EMBED_TS = 0x100  # stgcn_patch_embed: rows ordered (clip, joint, frame)
+BN_FROZEN = 0x200  # training entry points: BatchNorm on its running statistics (eval mode under autograd)
 
 STATUS = {0: "STGCN_OK", -1: "STGCN_ERR_ARG", -2: "STGCN_ERR_UNSUPPORTED",
           -3: "STGCN_ERR_WORKSPACE", -4: "STGCN_ERR_HIP"}
@@ -54,9 +55,9 @@ PROTOTYPES = {
     "stgcn_patch_embed": (c_int, [_P] * 5 + [c_int] * 5 + [c_uint, _P]),
     "stgcn_step_stats": (c_int, [_P, c_int, _P, c_int, c_int, c_long, c_float, _P, _P, _P, c_int, c_int, _P]),
     "stgcn_agcn_train_ws_bytes": (c_size_t, [c_int] * 7),
-    "stgcn_agcn_forward_train": (c_int, [_P] * 18 + [c_float, c_float, _P, _P, c_size_t] + [_P] * 4 + [c_int] * 7 + [_P]),
+    "stgcn_agcn_forward_train": (c_int, [_P] * 18 + [c_float, c_float, _P, _P, c_size_t] + [_P] * 4 + [c_int] * 7 + [c_uint, _P]),
     "stgcn_agcn_backward_ws_bytes": (c_size_t, [c_int] * 7),
-    "stgcn_agcn_backward_train": (c_int, [_P] * 34 + [_P, c_size_t] + [c_int] * 7 + [_P]),
+    "stgcn_agcn_backward_train": (c_int, [_P] * 34 + [_P, c_size_t] + [c_int] * 7 + [c_uint, _P]),
     "stgcn_tcn_train_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
     "stgcn_tcn_forward_train": (c_int, [_P] * 7 + [c_float, c_float, _P, c_size_t] + [_P] * 4 + [c_int] * 7 + [c_uint, _P]),
     "stgcn_tcn_backward_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),

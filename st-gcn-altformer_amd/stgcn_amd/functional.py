@@ -224,13 +224,15 @@ def stem_forward(x, A_eff, Wa, ba, Wb, bb, prep, t_shift, C, K, math=MATH_F32, o
 
 
 def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_bn, momentum=0.1, eps=BN_EPS,
-                       save=False):
+                       save=False, frozen=False):
     """Training-mode forward of unit_agcn (batch-statistics BatchNorm; running buffers of `bn` / `down_bn` are
     updated in place like torch does).  bn / down_bn: (weight, bias, running_mean, running_var) tensors.
     Returns (y, P); with ``save`` (y, P, zm, zd, stats): stats = batch mean / invstd of both BatchNorms (4*Cout) and, on
     the stem class's moments path, the 63 feature moments behind them (STGCN_AGCN_SAVE_STATS_FLOATS);
     zm, zd = the pre-BatchNorm branches, kept only with ``save="branches"`` (else None: the stem shape class then runs
-    the moments path, which never writes them, and its backward works from y, dy and the moments)."""
+    the moments path, which never writes them, and its backward works from y, dy and the moments).
+    ``frozen``: BatchNorm on its RUNNING statistics (eval mode under autograd): nothing is updated; stats = running mean /
+    invstd, for agcn_backward_train(..., frozen=True)."""
     dev = x.device
     N, Cin, T, V = x.shape
     S, inter_c, _ = Wa.shape
@@ -238,7 +240,7 @@ def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_
     y = torch.empty(N, Cout, T, V, device=dev, dtype=torch.float32)
     P = torch.empty(N, S, V, V, device=dev, dtype=torch.float32)
     branches = save == "branches"            # keep zm / zd (the materialising path); save=True keeps the statistics only
-    nbytes = _capi.lib().stgcn_agcn_train_ws_bytes(N, Cin, Cout, T, V, S, 1 if (branches or down_bn is None) else 0)
+    nbytes = _capi.lib().stgcn_agcn_train_ws_bytes(N, Cin, Cout, T, V, S, 1 if (branches or down_bn is None or frozen) else 0)
     ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
     d = down_bn if down_bn is not None else (None, None, None, None)
     zm = torch.empty_like(y) if branches else None
@@ -252,7 +254,7 @@ def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_
                    *[_dev_ptr(t, "down_bn", dev) for t in d], c_float(momentum), c_float(eps), _dev_ptr(P, "P"),
                    c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), _dev_ptr(y, "y"), _dev_ptr(zm, "save_zm"),
                    _dev_ptr(zd, "save_zd"), _dev_ptr(stats, "save_stats"), c_int(N), c_int(Cin), c_int(Cout),
-                   c_int(T), c_int(V), c_int(inter_c), c_int(S), _stream(dev))
+                   c_int(T), c_int(V), c_int(inter_c), c_int(S), c_uint(_capi.BN_FROZEN if frozen else 0), _stream(dev))
     return (y, P, zm, zd, stats) if save else (y, P)
 
 
@@ -263,11 +265,12 @@ def agcn_backward_supported(N, Cin, Cout, T, V, S) -> bool:
 
 
 def agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, zm, zd, bn_weight, bn_bias, dbn_weight,
-                        dbn_bias, stats, dy, need_dx=False, y=None):
+                        dbn_bias, stats, dy, need_dx=False, y=None, frozen=False):
     """Gradients of the training-mode unit_agcn forward.  zm / zd: the saved pre-BatchNorm branches, or None.  y: the
     forward's output — with it (and zm = zd = None, stats from a moments-path forward) the stem class runs its
     one-pass moment form; otherwise the GEMM chain, which rebuilds missing branches in the call's workspace.
-    Wdown / bdown / dbn_* None = identity residual (Cin == Cout).
+    Wdown / bdown / dbn_* None = identity residual (Cin == Cout).  ``frozen``: the forward ran on running statistics
+    (stats = running mean / invstd): they are constants of the backward (GEMM chain).
     Returns a dict keyed dWa, dba, dWb, dbb, dWd, dbd, dgamma, dbeta, dPA, plus dWdown, dbdown, ddgamma, ddbeta with a
     down branch and dx with ``need_dx`` (the input gradient, model/ST_TR/ST_TR_new.py:355-372)."""
     dev = x.device
@@ -299,21 +302,23 @@ def agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, zm, z
                    *[o(k) for k in ("dWa", "dba", "dWb", "dbb", "dWd", "dbd", "dWdown", "dbdown", "dgamma",
                                     "dbeta", "ddgamma", "ddbeta", "dPA", "dx")],
                    c_void_p(ws.data_ptr()), c_size_t(ws.numel() * 8), c_int(N), c_int(Cin), c_int(Cout), c_int(T),
-                   c_int(V), c_int(inter_c), c_int(S), _stream(dev))
+                   c_int(V), c_int(inter_c), c_int(S), c_uint(_capi.BN_FROZEN if frozen else 0), _stream(dev))
     return g
 
 
-def tcn_forward_train(x, W, conv_bias, bn, stride=1, math=MATH_F32, momentum=0.1, eps=BN_EPS, save=False):
+def tcn_forward_train(x, W, conv_bias, bn, stride=1, math=MATH_F32, momentum=0.1, eps=BN_EPS, save=False, frozen=False):
     """Training-mode forward of Unit2D(dim=2, dropout=0): raw conv -> batch statistics -> normalise -> ReLU.
 
-    ``save=True`` also returns what the backward needs: (y, z = conv_t(x)+b, batch mean, batch invstd)."""
+    ``save=True`` also returns what the backward needs: (y, z = conv_t(x)+b, batch mean, batch invstd).
+    ``frozen``: normalise with the RUNNING statistics instead (eval mode under autograd; nothing is updated, mean / invstd
+    returned are the running ones)."""
     dev = x.device
     N, Cin, T, V = x.shape
     Cout, _, K = W.shape
     Tout = tcn_out_frames(T, K, stride)
     if Tout < 1:
         raise ValueError(f"temporal conv: T={T}, K={K}, stride={stride} leaves no output frame")
-    fl = _flags(math, False)
+    fl = _flags(math, False) | (_capi.BN_FROZEN if frozen else 0)
     nbytes = _capi.lib().stgcn_tcn_train_ws_bytes(N, Cin, Cout, T, V, K, stride, fl)
     ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
     y = torch.empty(N, Cout, Tout, V, device=dev, dtype=torch.float32)
@@ -330,12 +335,12 @@ def tcn_forward_train(x, W, conv_bias, bn, stride=1, math=MATH_F32, momentum=0.1
 
 
 def tcn_backward_train(x, W, z, bn_weight, bn_bias, mean, invstd, dy, stride=1, math=MATH_F32, need_dx=True,
-                       has_bias=True):
+                       has_bias=True, frozen=False):
     """Backward of the training-mode Unit2D forward: returns (dx | None, dW (Cout,Cin,K), dbias | None, dgamma, dbeta)."""
     dev = x.device
     N, Cin, T, V = x.shape
     Cout, _, K = W.shape
-    fl = _flags(math, False)
+    fl = _flags(math, False) | (_capi.BN_FROZEN if frozen else 0)   # frozen: mean / invstd are constants (running statistics)
     nbytes = _capi.lib().stgcn_tcn_backward_ws_bytes(N, Cin, Cout, T, V, K, stride, fl)
     ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
     dx = torch.empty_like(x) if need_dx else None

@@ -50,10 +50,9 @@ def _check_input(mod: nn.Module, x: torch.Tensor, backward_ok: bool = False, bn_
 
     ``bn_training``: whether the module's BatchNorm(s) run on batch statistics (``self.bn.training`` — the reference's
     nn.BatchNorm2d decides per sub-module, so ``model.train()`` followed by ``bn.eval()`` freezes the statistics there
-    and must do so here).  Autograd exists for batch-statistics mode only (the training scripts' case,
-    train_sttran.py:176-191); with running statistics the kernels write plain tensors without a grad_fn, so a call that
-    expects gradients is refused rather than silently cut out of the graph (wrap inference in ``torch.no_grad()`` as
-    the reference's validation loops do, train_sttran.py:207-210)."""
+    and must do so here).  Autograd exists for both modes: batch statistics (the training scripts' case,
+    train_sttran.py:176-191) and running statistics (eval mode with gradients enabled — frozen-BatchNorm fine-tuning,
+    saliency; STGCN_BN_FROZEN); only Unit2D(dim=3) has no backward."""
     if not x.is_cuda:
         raise RuntimeError(
             f"{type(mod).__name__}: input is on {x.device}; the HIP path runs on the GPU only "
@@ -65,11 +64,6 @@ def _check_input(mod: nn.Module, x: torch.Tensor, backward_ok: bool = False, bn_
     if bn_training is None:
         bn_training = mod.training
     if _wants_grad(mod, x):
-        if not bn_training:
-            raise NotImplementedError(
-                f"{type(mod).__name__}: gradients were requested through running-statistics (eval-mode) BatchNorm. The HIP "
-                "backward covers batch-statistics mode (module.train()) only; run inference under torch.no_grad(), or "
-                "set requires_grad_(False) on the stem's parameters and input")
         if not backward_ok:
             raise NotImplementedError(
                 f"{type(mod).__name__}: no HIP backward for this configuration (Unit2D(dim=3)); the dim=2 temporal block "
@@ -128,10 +122,11 @@ class FusedStemOutput(torch.Tensor):
 
 # ----------------------------------------------------------------------------------------
 class _Unit2DTrainFn(torch.autograd.Function):
-    """relu(BatchNorm_batch(conv_t(x) + b)) with the HIP forward and backward (model/net.py:47-57 in .train())."""
+    """relu(BatchNorm(conv_t(x) + b)) with the HIP forward and backward (model/net.py:47-57): batch statistics in
+    .train(), running statistics (``frozen``: constants of the backward) in .eval() under autograd."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, bn_weight, bn_bias, running_mean, running_var, stride, mode, momentum, eps):
+    def forward(ctx, x, weight, bias, bn_weight, bn_bias, running_mean, running_var, stride, mode, momentum, eps, frozen=False):
         Cout, Cin, K = weight.shape[0], weight.shape[1], weight.shape[2]
         W = weight.detach().reshape(Cout, Cin, K).contiguous()
         bnw = bn_weight.detach() if bn_weight is not None else None
@@ -139,18 +134,18 @@ class _Unit2DTrainFn(torch.autograd.Function):
             raise NotImplementedError("Unit2D: the HIP training path needs an affine BatchNorm")
         y, z, mean, invstd = F.tcn_forward_train(x.detach(), W, None if bias is None else bias.detach(),
                                                  (bnw, bn_bias.detach(), running_mean, running_var), stride, mode,
-                                                 momentum, eps, save=True)
+                                                 momentum, eps, save=True, frozen=frozen)
         ctx.save_for_backward(x.detach(), W, z, bnw, bn_bias.detach(), mean, invstd)
-        ctx.meta = (stride, mode, bias is not None, tuple(weight.shape))
+        ctx.meta = (stride, mode, bias is not None, tuple(weight.shape), frozen)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, W, z, bnw, bnb, mean, invstd = ctx.saved_tensors
-        stride, mode, has_bias, wshape = ctx.meta
+        stride, mode, has_bias, wshape, frozen = ctx.meta
         dx, dW, db, dgamma, dbeta = F.tcn_backward_train(x, W, z, bnw, bnb, mean, invstd, dy.contiguous(), stride, mode,
-                                                         need_dx=ctx.needs_input_grad[0], has_bias=has_bias)
-        return (dx, dW.view(wshape), db if has_bias else None, dgamma, dbeta, None, None, None, None, None, None)
+                                                         need_dx=ctx.needs_input_grad[0], has_bias=has_bias, frozen=frozen)
+        return (dx, dW.view(wshape), db if has_bias else None, dgamma, dbeta, None, None, None, None, None, None, None)
 
 
 class _AgcnTrainFn(torch.autograd.Function):
@@ -164,11 +159,12 @@ class _AgcnTrainFn(torch.autograd.Function):
         has_down = mod._has_down()
         d = mod.down[1] if has_down else None
         xd = x.detach()
+        frozen = not mod._bn_training()              # .eval() under autograd: running statistics, constants of the backward
         y, P, zm, zd, stats = F.agcn_forward_train(
             xd, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"], st["bdown"],
             (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var),
             (d.weight.detach(), d.bias.detach(), d.running_mean, d.running_var) if has_down else None,
-            bn.momentum, bn.eps, save=True)
+            bn.momentum, bn.eps, save=True, frozen=frozen)
         # (zm, zd are None: the stem shape class derives its BatchNorm statistics from feature moments and writes
         #  neither branch; its backward works from y — which the consumer keeps anyway — dy and those moments)
         saved = [xd, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], P, bn.weight.detach(),
@@ -178,6 +174,7 @@ class _AgcnTrainFn(torch.autograd.Function):
         ctx.save_for_backward(*saved)
         ctx.S = mod.num_subset
         ctx.has_down = has_down
+        ctx.frozen = frozen
         mod.last_attention = P
         return y
 
@@ -188,7 +185,7 @@ class _AgcnTrainFn(torch.autograd.Function):
         Wdown, bdown, dbnw, dbnb = t[13:17] if ctx.has_down else (None, None, None, None)
         need_dx = ctx.needs_input_grad[1]
         g = F.agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, None, None, bnw, bnb, dbnw, dbnb, stats,
-                                  dy.contiguous(), need_dx=need_dx, y=y)
+                                  dy.contiguous(), need_dx=need_dx, y=y, frozen=ctx.frozen)
         S = ctx.S
         out = [g["dPA"]]
         for w, b in (("dWa", "dba"), ("dWb", "dbb"), ("dWd", "dbd")):
@@ -356,7 +353,8 @@ class unit_agcn(nn.Module):
         if x.shape[3] != self.PA.shape[-1]:
             raise RuntimeError(f"unit_agcn: input has {x.shape[3]} joints, adjacency has {self.PA.shape[-1]}")
         st = self._staged(x.device)
-        if not bn_training and self._fusable(x):
+        wants = _wants_grad(self, x)
+        if not bn_training and not wants and self._fusable(x):
             if not F._is_channels_last(x):     # the permuted (N,T,V,C) batch of ST_GCN_AltFormer.py:62-68 is read in place
                 x = x.contiguous()
             t = self._fused_tcn
@@ -373,8 +371,8 @@ class unit_agcn(nn.Module):
             self.last_attention = P
             return FusedStemOutput.wrap(out, t)   # only `t` (Unit2D.forward) can take it; any other use raises
         x = x.contiguous()
-        if bn_training:
-            return self._forward_train(x, st)
+        if bn_training or wants:             # (eval mode under autograd: the same kernels on the running statistics)
+            return self._forward_train(x, st, frozen=not bn_training)
         y, P = F.agcn_forward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"],
                               st["Wdown"], st["bdown"], st["bn_scale"], st["bn_shift"], st["down_scale"],
                               st["down_shift"])
@@ -392,11 +390,14 @@ class unit_agcn(nn.Module):
             ps += [self.down[0].weight, self.down[0].bias, self.down[1].weight, self.down[1].bias]
         return ps + [self.bn.weight, self.bn.bias]
 
-    def _forward_train(self, x, st):
-        """Batch-statistics BatchNorm forward (model/unit_agcn.py:91-92 with self.training); updates running buffers."""
+    def _forward_train(self, x, st, frozen=False):
+        """Batch-statistics BatchNorm forward (model/unit_agcn.py:91-92 with self.training); updates running buffers.
+        ``frozen`` (eval mode under autograd): running statistics, nothing updated."""
         bn = self.bn
-        if bn.momentum is None or not bn.track_running_stats:
+        if not frozen and (bn.momentum is None or not bn.track_running_stats):
             raise NotImplementedError("unit_agcn: training-mode BatchNorm needs momentum and running statistics")
+        if frozen and not bn.track_running_stats:
+            raise NotImplementedError("unit_agcn: eval-mode BatchNorm without running statistics is not covered")
         if _wants_grad(self, x):                   # autograd: HIP forward + HIP backward (fused kernel or GEMM chain)
             N, C, T, V = x.shape
             if not F.agcn_backward_supported(N, C, self.out_channels, T, V, self.num_subset) \
@@ -405,7 +406,9 @@ class unit_agcn(nn.Module):
                     "unit_agcn: the HIP backward covers V <= 64 joints and coff_embedding >= 4; this call is outside it")
             y = _AgcnTrainFn.apply(self, x, *self._train_params())
             with torch.no_grad():                  # (one launch for both counters)
-                if self._has_down():
+                if frozen:
+                    pass
+                elif self._has_down():
                     torch._foreach_add_([bn.num_batches_tracked, self.down[1].num_batches_tracked], 1)
                 else:
                     bn.num_batches_tracked += 1
@@ -497,20 +500,25 @@ class Unit2D(nn.Module):
             mode = MATH_F32_VALU
         if self.dropout.p > 0 and self.dropout.training:
             x = self.dropout(x)              # torch's RNG-driven op (the stem always uses p = 0, model/net.py:45)
-        if bn_training:
+        wants = _wants_grad(self, x)
+        if bn_training or wants:             # (eval mode under autograd: the same kernels on the running statistics)
             bn = self.bn
-            if bn.momentum is None or not bn.track_running_stats:
+            if bn_training and (bn.momentum is None or not bn.track_running_stats):
                 raise NotImplementedError("Unit2D: training-mode BatchNorm needs momentum and running statistics")
+            if not bn_training and not bn.track_running_stats:
+                raise NotImplementedError("Unit2D: eval-mode BatchNorm without running statistics is not covered")
             c = self.conv
-            if _wants_grad(self, x):         # autograd: HIP forward + HIP backward (tcn_backward.hip)
+            if wants:                        # autograd: HIP forward + HIP backward (tcn_backward.hip)
                 y = _Unit2DTrainFn.apply(x, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                         self.stride, mode, bn.momentum, bn.eps)
+                                         self.stride, mode, bn.momentum if bn.momentum is not None else 0.0, bn.eps,
+                                         not bn_training)
             else:
                 W = c.weight.detach().reshape(c.out_channels, c.in_channels, self.kernel_size).contiguous()
                 y = F.tcn_forward_train(x, W, c.bias, (bn.weight, bn.bias, bn.running_mean, bn.running_var), self.stride,
                                         mode, bn.momentum, bn.eps)
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
+            if bn_training:
+                with torch.no_grad():
+                    bn.num_batches_tracked += 1
         else:
             st = self._staged(x.device)
             y = F.tcn_forward_packed(x, self._packed(st, mode), st["shift"], self.conv.out_channels,

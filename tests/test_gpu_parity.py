@@ -366,7 +366,7 @@ def test_fused_stem_result_cannot_be_misused(dev):
 
 def test_batchnorm_mode_follows_the_bn_submodules(dev):
     """model.train() followed by bn.eval() (frozen-BN fine-tuning) freezes the statistics in the reference
-    (nn.BatchNorm2d looks at its own flag); same here, and mixed modes / eval-mode autograd are refused."""
+    (nn.BatchNorm2d looks at its own flag); same here; mixed modes are refused, eval-mode autograd is served."""
     g = load_golden("stem_shre_T180")
     gcn = build_gcn(g, 3, 128, dev)
     tcn = build_tcn(g, 128, 128, 9, 1, True, dev, "f32")
@@ -383,8 +383,9 @@ def test_batchnorm_mode_follows_the_bn_submodules(dev):
         with pytest.raises(NotImplementedError):
             gcn(x)                                   # bn on batch statistics, down[1] frozen
         gcn.eval(); tcn.eval()
-    with pytest.raises(NotImplementedError):
-        tcn(gcn(x))                                  # grad-enabled call through running-statistics BatchNorm
+    out = tcn(gcn(x))                                # grad-enabled call through running-statistics BatchNorm: differentiable
+    assert out.grad_fn is not None and torch.equal(tcn.bn.running_mean, rm)     # (test_eval_mode_backward_* check the values)
+    parity_gate(out.detach(), ref, 1e-5, "eval mode under autograd vs inference kernels")
     for p in list(gcn.parameters()) + list(tcn.parameters()):
         p.requires_grad_(False)
     assert torch.equal(tcn(gcn(x)), ref)             # nothing wants a gradient: plain inference, no no_grad needed
@@ -778,6 +779,101 @@ def test_unit_agcn_backward_vs_oracle(N, T, V, cout, dev):
     parity_gate(y.detach(), yr.detach(), 1e-4, "training-mode forward")
     (y * G.to(dev)).sum().backward()
     _compare_grads(_agcn_module_grads(gcn), ref, 1e-4)
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "f32"])
+@pytest.mark.parametrize("cin,cout,K,stride,N,T,V", [(128, 128, 9, 1, 3, 21, 22), (64, 128, 9, 2, 2, 21, 22), (32, 64, 3, 1, 2, 9, 25)])
+def test_eval_mode_backward_unit2d_vs_oracle(cin, cout, K, stride, N, T, V, math, dev):
+    """the reference's nn.BatchNorm2d stays differentiable in .eval() (model/net.py:52) — frozen-BatchNorm
+    fine-tuning, saliency.  Running statistics are constants of the backward (STGCN_BN_FROZEN): every gradient against
+    autograd through the fp64 oracle in eval mode; the buffers must not move."""
+    from stgcn_amd import Unit2D, set_math_mode
+    from oracle import stgcn_oracle as so
+    torch.manual_seed(1900 + cin + K + V)
+    gen = torch.Generator().manual_seed(1901 + cin + K + V)
+    m = Unit2D(cin, cout, kernel_size=K, stride=stride)
+    with torch.no_grad():
+        m.bn.weight.copy_(torch.rand(cout, generator=gen) + 0.5)
+        m.bn.bias.copy_(torch.randn(cout, generator=gen) * 0.2)
+        m.bn.running_mean.copy_(torch.randn(cout, generator=gen) * 0.3)
+        m.bn.running_var.copy_(torch.rand(cout, generator=gen) * 1.5 + 0.25)
+        m.conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
+    set_math_mode(m, math)
+    tp = so.tcn_params_from_state(m.state_dict(), stride=stride).to(torch.float64)
+    x = torch.randn(N, cin, T, V, generator=gen)
+    leaves = [tp.conv_w, tp.bn.weight, tp.bn.bias, tp.conv_b]
+    for t in leaves:
+        t.requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    yr = so.tcn_forward(xr, tp, training=False)
+    G = _kink_free_cotangent(yr, gen)
+    grads = torch.autograd.grad((yr * G.double()).sum(), leaves + [xr])
+    m = m.to(dev).eval()
+    rm, rv, nb = m.bn.running_mean.clone(), m.bn.running_var.clone(), m.bn.num_batches_tracked.clone()
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    parity_gate(y.detach(), yr.detach(), 1e-4, "eval-mode forward under autograd")
+    (y * G.to(dev)).sum().backward()
+    assert torch.equal(m.bn.running_mean, rm) and torch.equal(m.bn.running_var, rv) and torch.equal(m.bn.num_batches_tracked, nb)
+    _grad_gate(m.conv.weight.grad.reshape(cout, cin, K), grads[0], 1e-4, "dW")
+    _grad_gate(m.bn.weight.grad, grads[1], 1e-4, "dgamma")
+    _grad_gate(m.bn.bias.grad, grads[2], 1e-4, "dbeta")
+    _grad_gate(m.conv.bias.grad, grads[3], 1e-4, "dbias")       # NOT zero behind a frozen BatchNorm
+    _grad_gate(xd.grad, grads[-1], 1e-4, "dx")
+
+
+@pytest.mark.parametrize("cin,cout,N,T,V,want_dx", [(3, 128, 3, 20, 22, False), (64, 64, 2, 12, 22, True), (64, 128, 2, 9, 25, True)])
+def test_eval_mode_backward_unit_agcn_vs_oracle(cin, cout, N, T, V, want_dx, dev):
+    """Same for unit_agcn (model/unit_agcn.py:54,91 in .eval()): stem class (the moment form is the batch-statistics closed
+    form, so frozen statistics take the GEMM chain), identity residual and down branch, with dx."""
+    from oracle import stgcn_oracle as so
+    gcn, _, gp, _, gen = _random_stem(V, None, 2100 + cin + cout + T + V, dev, cin=cin, c=cout)
+    gp = gp.to(torch.float64)
+    leaves = _agcn_oracle_leaves(gp)
+    x = torch.randn(N, cin, T, V, generator=gen)
+    xr = x.double().requires_grad_(want_dx)
+    yr = so.agcn_forward(xr, gp, training=False)
+    G = _kink_free_cotangent(yr, gen)
+    names = sorted(leaves)
+    got = torch.autograd.grad((yr * G.double()).sum(), [leaves[k] for k in names] + ([xr] if want_dx else []))
+    ref = dict(zip(names, got))
+    gcn.eval()
+    bufs = [b.clone() for b in gcn.buffers()]
+    xd = x.to(dev).requires_grad_(want_dx)
+    y = gcn(xd)
+    parity_gate(y.detach(), yr.detach(), 1e-4, "eval-mode forward under autograd")
+    (y * G.to(dev)).sum().backward()
+    assert all(torch.equal(a, b) for a, b in zip(bufs, gcn.buffers())), "eval-mode backward moved a buffer"
+    grads = _agcn_module_grads(gcn)
+    bad = []
+    for k in names:       # (behind frozen statistics the conv_d / down biases have real gradients: plain per-tensor gate)
+        g, r = grads[k].reshape(ref[k].shape).double().cpu(), ref[k].double().cpu()
+        scale = r.abs().max().item()
+        if k.startswith("a_b"):                    # conv_a's bias: constant shift under the column soft-max, zero gradient
+            scale = max(scale, ref["a_w" + k[3:]].abs().max().item())
+        err = (g - r).abs().max().item()
+        if err > 1e-4 * max(scale, 1e-30):
+            bad.append(f"d{k}: err {err:.3e} vs 1e-4*{scale:.3e}")
+    assert not bad, "; ".join(bad)
+    if want_dx:
+        _grad_gate(xd.grad, got[-1], 1e-4, "dx")
+
+
+def test_eval_mode_backward_through_the_stem(dev):
+    """tcn0(gcn0(x)) in .eval() with gradients enabled and stem fusion on: the fused inference kernel has no backward, so
+    the call takes the differentiable path; the result equals the fused kernel's within the fp32 contract."""
+    from stgcn_amd import enable_stem_fusion
+    gcn, tcn, gp, tp, gen = _random_stem(22, None, 77, dev)
+    enable_stem_fusion(gcn, tcn)
+    x = torch.randn(4, 3, 30, 22, generator=gen).to(dev)
+    with torch.no_grad():
+        ref = tcn(gcn(x))
+    out = tcn(gcn(x))
+    assert out.grad_fn is not None
+    parity_gate(out.detach(), ref, 1e-4, "eval-mode stem under autograd vs fused inference kernel")
+    out.square().mean().backward()
+    for name, p in list(gcn.named_parameters()) + list(tcn.named_parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
 
 
 @pytest.mark.parametrize("cin,cout,N,T,V,layout", [

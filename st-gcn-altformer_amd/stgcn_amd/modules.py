@@ -12,6 +12,7 @@ in-place edit invalidates it automatically.
 from __future__ import annotations
 
 import math
+import warnings
 import os
 from typing import Optional
 
@@ -354,6 +355,11 @@ class unit_agcn(nn.Module):
             raise RuntimeError(f"unit_agcn: input has {x.shape[3]} joints, adjacency has {self.PA.shape[-1]}")
         st = self._staged(x.device)
         wants = _wants_grad(self, x)
+        if wants and not bn_training and self._fused_tcn is not None and not getattr(self, "_warned_fusion_bypass", False):
+            object.__setattr__(self, "_warned_fusion_bypass", True)
+            warnings.warn("unit_agcn: eval-mode call with gradients enabled — taking the differentiable two-kernel path, not "
+                          "the fused inference kernel; wrap inference in torch.no_grad() (as train_sttran.py:207-210 does)",
+                          stacklevel=2)
         if not bn_training and not wants and self._fusable(x):
             if not F._is_channels_last(x):     # the permuted (N,T,V,C) batch of ST_GCN_AltFormer.py:62-68 is read in place
                 x = x.contiguous()

@@ -316,8 +316,10 @@ def main():
             workload = (f"BASELINE configs[4]: ONE synthetic batch (N={n_global},3,{T},{V}) DP-sharded over {world} GPU(s), "
                         f"{n_local} clips on this rank in sub-batches of <= {sub}")
         else:
-            workload = (f"SHREC'17-shape stem forward: V={V}, T={T}, {n_local} clips/GPU "
-                        f"(BASELINE configs[1] batch at 1 GPU; weak-scaled)")
+            named = {(256, 180, 22): "BASELINE configs[1] batch at 1 GPU", (512, 500, 22): "BASELINE configs[2] (DHG, long clips)",
+                     (256, 200, 46): "BASELINE configs[3] (LMDHG two-hand graph)"}.get((n_local, T, V), "not a BASELINE config")
+            workload = (f"{'SHREC' if V == 22 else 'LMDHG'}-graph stem forward: V={V}, T={T}, {n_local} clips/GPU "
+                        f"({named}; weak-scaled)")
         line = {
             "metric": "clips/sec ST-GCN forward", "value": round(value, 1), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

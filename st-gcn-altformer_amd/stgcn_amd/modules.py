@@ -301,8 +301,14 @@ class unit_agcn(nn.Module):
                 device=device, dtype=torch.float32).contiguous()
             stack_b = lambda convs: torch.stack([c.bias for c in convs]).to(device=device, dtype=torch.float32).contiguous()
             st = {"key": key}
-            # A = self.A.cuda(dev) + self.PA  (model/unit_agcn.py:75-76); uploaded once, not per call
-            st["A_eff"] = (self.A.to(device=device, dtype=torch.float32) + self.PA.to(device)).contiguous()
+            # A = self.A.cuda(dev) + self.PA  (model/unit_agcn.py:75-76).  The constant A is uploaded once per device and
+            # version — not per call, and not per restage either: in training every step restages (PA moved), and a
+            # host-to-device copy there would synchronise the host each step and forbid capturing the step in a HIP graph
+            akey = (device, self.A._version, id(self.A))
+            if getattr(self, "_A_dev_key", None) != akey:
+                object.__setattr__(self, "_A_dev", self.A.to(device=device, dtype=torch.float32).contiguous())
+                object.__setattr__(self, "_A_dev_key", akey)
+            st["A_eff"] = (self._A_dev + self.PA.to(device)).contiguous()
             st["Wa"], st["ba"] = stack_w(self.conv_a), stack_b(self.conv_a)
             st["Wb"], st["bb"] = stack_w(self.conv_b), stack_b(self.conv_b)
             st["Wd"], st["bd"] = stack_w(self.conv_d), stack_b(self.conv_d)

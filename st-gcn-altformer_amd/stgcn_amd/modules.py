@@ -297,10 +297,30 @@ class unit_agcn(nn.Module):
             return self._cache
         with torch.no_grad():
             S = self.num_subset
-            stack_w = lambda convs: torch.stack([c.weight.reshape(c.out_channels, c.in_channels) for c in convs]).to(
-                device=device, dtype=torch.float32).contiguous()
-            stack_b = lambda convs: torch.stack([c.bias for c in convs]).to(device=device, dtype=torch.float32).contiguous()
             st = {"key": key}
+            # the 18 embedding / expansion tensors as ONE concatenation (one launch; six stacks were six), viewed per group:
+            # a stack of equally shaped tensors is the concatenation of their flattened values
+            groups = [(self.conv_a, "Wa", "ba"), (self.conv_b, "Wb", "bb"), (self.conv_d, "Wd", "bd")]
+            pieces, views, off = [], [], 0
+            w0 = self.conv_a[0].weight
+            zkey = (w0.device, w0.dtype)
+            if getattr(self, "_zpad_key", None) != zkey:     # every group starts 256-byte aligned, like an allocation
+                object.__setattr__(self, "_zpad", torch.zeros(64, device=w0.device, dtype=w0.dtype))
+                object.__setattr__(self, "_zpad_key", zkey)
+            for convs, wn, bn_ in groups:
+                c0 = convs[0]
+                for name, shape, ts in ((wn, (len(convs), c0.out_channels, c0.in_channels), [c.weight for c in convs]),
+                                        (bn_, (len(convs), c0.out_channels), [c.bias for c in convs])):
+                    n = math.prod(shape)
+                    pieces += [t.reshape(-1) for t in ts]
+                    views.append((name, shape, off, n))
+                    pad = -n % 64
+                    if pad:
+                        pieces.append(self._zpad[:pad])
+                    off += n + pad
+            flat = torch.cat(pieces).to(device=device, dtype=torch.float32)
+            for name, shape, o, n in views:
+                st[name] = flat[o:o + n].view(shape)
             # A = self.A.cuda(dev) + self.PA  (model/unit_agcn.py:75-76).  The constant A is uploaded once per device and
             # version — not per call, and not per restage either: in training every step restages (PA moved), and a
             # host-to-device copy there would synchronise the host each step and forbid capturing the step in a HIP graph
@@ -309,23 +329,30 @@ class unit_agcn(nn.Module):
                 object.__setattr__(self, "_A_dev", self.A.to(device=device, dtype=torch.float32).contiguous())
                 object.__setattr__(self, "_A_dev_key", akey)
             st["A_eff"] = (self._A_dev + self.PA.to(device)).contiguous()
-            st["Wa"], st["ba"] = stack_w(self.conv_a), stack_b(self.conv_a)
-            st["Wb"], st["bb"] = stack_w(self.conv_b), stack_b(self.conv_b)
-            st["Wd"], st["bd"] = stack_w(self.conv_d), stack_b(self.conv_d)
-            bn = self.bn
-            st["bn_scale"], st["bn_shift"] = F.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                                       None, bn.eps)
+            # folded running-statistics BatchNorms: what the inference kernels take — made on first use (_folded), not per
+            # training step
+            st["bn_scale"] = st["bn_shift"] = st["down_scale"] = st["down_shift"] = None
             if self._has_down():
                 dc, dbn = self.down[0], self.down[1]
                 st["Wdown"] = dc.weight.reshape(dc.out_channels, dc.in_channels).to(
                     device=device, dtype=torch.float32).contiguous()
                 st["bdown"] = dc.bias.to(device=device, dtype=torch.float32).contiguous()
-                st["down_scale"], st["down_shift"] = F.bn_fold(dbn.weight, dbn.bias, dbn.running_mean,
-                                                               dbn.running_var, None, dbn.eps)
             else:
-                st["Wdown"] = st["bdown"] = st["down_scale"] = st["down_shift"] = None
+                st["Wdown"] = st["bdown"] = None
             assert S == st["Wd"].shape[0]
         self._cache = st
+        return st
+
+    def _folded(self, st):
+        """scale / shift of the running-statistics BatchNorms (eval forward), cached in the staged set."""
+        if st["bn_scale"] is None:
+            with torch.no_grad():
+                bn = self.bn
+                st["bn_scale"], st["bn_shift"] = F.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, None, bn.eps)
+                if self._has_down():
+                    dbn = self.down[1]
+                    st["down_scale"], st["down_shift"] = F.bn_fold(dbn.weight, dbn.bias, dbn.running_mean, dbn.running_var,
+                                                                   None, dbn.eps)
         return st
 
     def _bn_training(self) -> bool:
@@ -373,6 +400,7 @@ class unit_agcn(nn.Module):
             ts = t._staged(x.device)
             pkey = (st["key"], ts["key"], t.math_mode)
             if st.get("stem_key") != pkey:
+                self._folded(st)
                 st["stem_prep"] = F.stem_prepare(st["Wd"], st["bd"], st["Wdown"], st["bdown"], st["bn_scale"],
                                                  st["bn_shift"], st["down_scale"], st["down_shift"], ts["W"],
                                                  ts["scale"], t.math_mode)
@@ -385,6 +413,7 @@ class unit_agcn(nn.Module):
         x = x.contiguous()
         if bn_training or wants:             # (eval mode under autograd: the same kernels on the running statistics)
             return self._forward_train(x, st, frozen=not bn_training)
+        self._folded(st)
         y, P = F.agcn_forward(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"],
                               st["Wdown"], st["bdown"], st["bn_scale"], st["bn_shift"], st["down_scale"],
                               st["down_shift"])

@@ -24,11 +24,27 @@ struct Ws {
     float *U, *DU, *A, *B, *DA, *DB, *DP, *DS, *part, *bpart;
 };
 
+// Products with one C tile per clip and a long contraction (dW slices: K = T*V; joint Grams: K = C_in*T) are split along K
+// so that about a thousand workgroups run: parts [ksplit][N][m], summed in a fixed order.  The part buffer caps the split.
+constexpr size_t PART_CAP_FLOATS = (size_t)16 << 20;     // 64 MiB
+
 size_t part_floats(int N, int Cin, int Cout, int inter_c, int V) {
     size_t m = (size_t)Cout * Cin;
     if ((size_t)inter_c * Cin > m) m = (size_t)inter_c * Cin;
     if ((size_t)V * V > m) m = (size_t)V * V;
-    return (size_t)N * m;
+    const size_t one = (size_t)N * m;
+    return one * 16 <= PART_CAP_FLOATS ? one * 16 : (one > PART_CAP_FLOATS ? one : PART_CAP_FLOATS);
+}
+
+// split factor of a product with `tiles` C tiles per clip, contraction length K and m floats of C per clip
+int k_split(int N, int tiles, int K, size_t m, size_t part_cap) {
+    long long ks = 1024 / ((long long)N * tiles);
+    if (ks > 16) ks = 16;
+    if (ks > K / 128) ks = K / 128;                      // at least 128 contraction steps per part
+    const long long fit = (long long)(part_cap / ((size_t)N * m));
+    if (ks > fit) ks = fit;
+    if ((long long)N * ks > 65535) ks = 65535 / N;
+    return ks < 1 ? 1 : (int)ks;
 }
 
 }  // namespace
@@ -60,11 +76,16 @@ int launch_agcn_bwd_generic(const float *x, const float *Pm, const float *A_eff,
         return launch_gemm_f32(g, N, st);
     };
     // sum over clips of dY[n] (rows x P) X[n]^T (cols x P)  ->  out (rows x cols);  bias gradient -> bout (rows)
+    const size_t part_cap = part_floats(N, Cin, Cout, inter_c, V);
     auto wgrad = [&](const float *dY, int rows, const float *X, int cols, float *out, float *bout) {
-        int r = gemm(dY, P, 1, (long long)rows * P, X, 1, P, (long long)cols * P, w.part, cols, 1, (long long)rows * cols, rows, cols,
-                     (int)P, nullptr, 1.f, 0);
+        const size_t m = (size_t)rows * cols;
+        GemmArgs g{dY, X, w.part, nullptr, rows, cols, (int)P, P, 1, (long long)rows * P, 1, P, (long long)cols * P, cols, 1,
+                   (long long)m, 1.f, 0};
+        g.ksplit = k_split(N, ceil_div(rows, 64) * ceil_div(cols, 64), (int)P, m, part_cap);
+        g.c_ss = (long long)N * (long long)m;             // parts [ksplit][N][rows*cols]
+        int r = launch_gemm_f32(g, N, st);
         if (r != STGCN_OK) return r;
-        r = launch_sum_parts(w.part, out, N, (size_t)rows * cols, st);
+        r = launch_sum_parts(w.part, out, N * g.ksplit, m, st);
         if (r != STGCN_OK || bout == nullptr) return r;
         r = launch_row_sum(dY, w.bpart, N * rows, (int)P, st);
         if (r != STGCN_OK) return r;
@@ -93,7 +114,16 @@ int launch_agcn_bwd_generic(const float *x, const float *Pm, const float *A_eff,
         if (dx != nullptr)        // dx += du P_s^T : B[k = w][n = v] = P_s[v][w]
             OK(gemm(w.DU, V, 1, (long long)Cin * P, Ps, 1, V, (long long)S * VV, dx, V, 1, (long long)Cin * P, R, V, V, nullptr, 1.f, 1));
         // dP = x^T du  (V x V per clip), dPA_s = sum over clips
-        OK(gemm(x, 1, V, (long long)Cin * P, w.DU, V, 1, (long long)Cin * P, w.DP, V, 1, VV, V, V, R, nullptr, 1.f, 0));
+        {
+            GemmArgs g{x, w.DU, w.DP, nullptr, V, V, R, 1, V, (long long)Cin * P, V, 1, (long long)Cin * P, V, 1, VV, 1.f, 0};
+            g.ksplit = k_split(N, ceil_div(V, 64) * ceil_div(V, 64), R, (size_t)VV, part_cap);
+            if (g.ksplit > 1) {                           // parts [ksplit][N][V*V] in the part buffer, summed per clip into DP
+                g.C = w.part;
+                g.c_ss = (long long)N * VV;
+            }
+            OK(launch_gemm_f32(g, N, st));
+            if (g.ksplit > 1) OK(launch_sum_parts(w.part, w.DP, g.ksplit, (size_t)N * VV, st));
+        }
         OK(launch_sum_parts(w.DP, dPA + (size_t)s * VV, N, (size_t)VV, st));
         OK(launch_softmax_bwd(Pm, A_eff, w.DP, w.DS, N, V, S, s, 1.f / (float)(inter_c * T), st));
         // embeddings a, b (recomputed)

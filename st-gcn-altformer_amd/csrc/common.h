@@ -226,6 +226,11 @@ struct GemmArgs {
     const float *nbias = nullptr;
     const float *cbias = nullptr;
     long long cb_sq = 0, cb_sr = 0, cb_sn = 0;
+    // optional split of the contraction index: part j of ksplit covers k in [j*kc, (j+1)*kc) (kc a multiple of the K chunk)
+    // and writes C + j*c_ss — the caller sums the parts in a fixed order (launch_sum_parts).  For products with a long K
+    // and a small C (the per-clip weight-gradient slices, the joint Gram matrices) whose one tile per clip left most CUs idle.
+    int ksplit = 1;
+    long long c_ss = 0;
 };
 int launch_gemm_f32(const GemmArgs &g, int batch, hipStream_t st);
 int launch_sum_parts(const float *part, float *out, int parts, size_t n, hipStream_t st);   // fixed order p = 0, 1, ...

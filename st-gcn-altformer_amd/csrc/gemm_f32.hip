@@ -29,16 +29,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     __shared__ float Bs[GK * BPAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int m0 = blockIdx.x * GT, n0 = blockIdx.y * GT, b = blockIdx.z;
+    const int ks = g.ksplit > 1 ? g.ksplit : 1;
+    const int m0 = blockIdx.x * GT, n0 = blockIdx.y * GT, b = blockIdx.z / ks, part = blockIdx.z - b * ks;
     const float *A = g.A + (size_t)b * g.a_sb;
     const float *B = g.B + (size_t)b * g.b_sb;
-    float *C = g.C + (size_t)b * g.c_sb;
+    float *C = g.C + (size_t)b * g.c_sb + (size_t)part * g.c_ss;
+    const int kc = ks > 1 ? ((g.K + ks - 1) / ks + GK - 1) / GK * GK : g.K;      // this part's share of K
+    const int k_lo = part * kc, k_hi = min(g.K, k_lo + kc);                       // (an empty part writes zeros)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool a_k_fast = g.a_sk == 1;     // consecutive threads along the unit-stride index of each operand
     const bool b_n_fast = g.b_sn == 1 || g.b_sk != 1;
-    for (int k0 = 0; k0 < g.K; k0 += GK) {
+    for (int k0 = k_lo; k0 < k_hi; k0 += GK) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < GT * GK / 256; ++i) {
@@ -46,14 +49,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             const int m = a_k_fast ? e / GK : e % GT, k = a_k_fast ? e % GK : e / GT;
             const int gm = m0 + m, gk = k0 + k;
             const int q = g.m_inner ? gm / g.m_inner : gm, r = g.m_inner ? gm - q * g.m_inner : 0;
-            As[m * APAD + k] = (gm < g.M && gk < g.K) ? A[(size_t)q * g.a_sm + (size_t)r * g.a_sm2 + (size_t)gk * g.a_sk] : 0.f;
+            As[m * APAD + k] = (gm < g.M && gk < k_hi) ? A[(size_t)q * g.a_sm + (size_t)r * g.a_sm2 + (size_t)gk * g.a_sk] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < GT * GK / 256; ++i) {
             const int e = tid + i * 256;
             const int k = b_n_fast ? e / GT : e % GK, n = b_n_fast ? e % GT : e / GK;
             const int gk = k0 + k, gn = n0 + n;
-            Bs[k * BPAD + n] = (gk < g.K && gn < g.N) ? B[(size_t)gk * g.b_sk + (size_t)gn * g.b_sn] : 0.f;
+            Bs[k * BPAD + n] = (gk < k_hi && gn < g.N) ? B[(size_t)gk * g.b_sk + (size_t)gn * g.b_sn] : 0.f;
         }
         __syncthreads();
         const float *ap = As + (wm * 32 + (lane & 31)) * APAD + (lane >> 5);
@@ -136,8 +139,11 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float *__restric
 
 int launch_gemm_f32(const GemmArgs &g, int batch, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || batch <= 0) return fail(STGCN_ERR_ARG, "gemm: empty problem");
-    if (batch > 65535 || ceil_div(g.N, GT) > 65535) return fail(STGCN_ERR_UNSUPPORTED, "gemm: grid too large");
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(g.M, GT), ceil_div(g.N, GT), batch), dim3(256), 0, st, g);
+    const int ks = g.ksplit > 1 ? g.ksplit : 1;
+    if ((long long)batch * ks > 65535 || ceil_div(g.N, GT) > 65535) return fail(STGCN_ERR_UNSUPPORTED, "gemm: grid too large");
+    if (ks > 1 && (g.accumulate || g.bias || g.nbias || g.cbias))
+        return fail(STGCN_ERR_ARG, "gemm: a split contraction writes plain partial sums (no bias, no accumulate)");
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(g.M, GT), ceil_div(g.N, GT), batch * ks), dim3(256), 0, st, g);
     STGCN_LAUNCH_CHECK("gemm_f32_kernel");
     return STGCN_OK;
 }

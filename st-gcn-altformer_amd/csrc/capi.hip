@@ -572,6 +572,9 @@ static unsigned tcn_dgrad_flags(int Cin, int Cout, int Tout, int V, int K, unsig
 // conv pads K-1-pad frames, which equals the forward's pad = (K-1)/2 when K is odd.  With an even K the forward drops a
 // frame (Tout = T-1) and that shortcut would write T-2 misaligned frames: even K runs the general VALU dgrad instead.
 static bool tcn_dgrad_by_forward(int K, int stride) { return stride == 1 && (K & 1) == 1; }
+// A stride-2 block with an odd K (TCN_GCN_unit's downsampling layers, model/ST_TR/ST_TR_new.py:362-372) runs its backward as the
+// stride-1 block's on dz upsampled with zero frames (launch_upsample2): matrix-core wgrad and dgrad instead of plain FMAs.
+static bool tcn_bwd_upsampled(int K, int stride) { return stride == 2 && (K & 1) == 1; }
 
 size_t stgcn_tcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags) {
     flags &= ~STGCN_BN_FROZEN;
@@ -579,10 +582,13 @@ size_t stgcn_tcn_backward_ws_bytes(int N, int Cin, int Cout, int T, int V, int K
     const int Tout = (T + 2 * ((K - 1) / 2) - K) / stride + 1;
     if (Tout < 1) return 0;
     size_t b = tcn_bwd_small_bytes(Cin, Cout) + align_up((size_t)N * Cout * Tout * V * sizeof(float), 256);
-    if (tcn_dgrad_by_forward(K, stride))
+    const bool up = tcn_bwd_upsampled(K, stride);
+    if (up) b += align_up((size_t)N * Cout * T * V * sizeof(float), 256);
+    const int es = up ? 1 : stride, eTout = up ? T : Tout;
+    if (tcn_dgrad_by_forward(K, es))
         b += align_up((size_t)Cout * Cin * K * sizeof(float), 256) +
-             align_up(tcn_packed_bytes(Cout, Cin, K, tcn_dgrad_flags(Cin, Cout, Tout, V, K, flags)), 256);
-    return b + tcn_wgrad_ws_bytes(N, Cin, Cout, T, V, K, stride, flags);
+             align_up(tcn_packed_bytes(Cout, Cin, K, tcn_dgrad_flags(Cin, Cout, eTout, V, K, flags)), 256);
+    return b + tcn_wgrad_ws_bytes(N, Cin, Cout, T, V, K, es, flags);
 }
 
 int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, const float *bn_weight,
@@ -621,11 +627,21 @@ int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, con
         rc = launch_doubles_to_floats(bsum, dbias, Cout, st);
         if (rc != STGCN_OK) return rc;
     }
+    int Tz = Tout;                               // frames of the gradient tensor the two conv gradients read
+    if (tcn_bwd_upsampled(K, stride)) {
+        float *dzu = (float *)p;
+        p += align_up((size_t)N * Cout * T * V * sizeof(float), 256);
+        rc = launch_upsample2(dz, dzu, (size_t)N * Cout, Tout, T, V, st);
+        if (rc != STGCN_OK) return rc;
+        dz = dzu;
+        stride = 1;
+        Tz = T;
+    }
     if (dx != nullptr) {
         if (tcn_dgrad_by_forward(K, stride)) {   // dx = conv_t(dz, flipped W): the forward kernels, raw output
             float *Wf = (float *)p;
             p += align_up((size_t)Cout * Cin * K * sizeof(float), 256);
-            const unsigned dfl = tcn_dgrad_flags(Cin, Cout, Tout, V, K, flags);
+            const unsigned dfl = tcn_dgrad_flags(Cin, Cout, Tz, V, K, flags);
             void *packed = p;
             p += align_up(tcn_packed_bytes(Cout, Cin, K, dfl), 256);
             hipLaunchKernelGGL(fill_ones_zeros_kernel, dim3(ceil_div(Cin, 256)), dim3(256), 0, st, ones, zeros, Cin);
@@ -634,18 +650,18 @@ int stgcn_tcn_backward_train(const float *x, const float *W, const float *z, con
             if (rc != STGCN_OK) return rc;
             rc = launch_tcn_pack(Wf, ones, packed, Cout, Cin, K, dfl, st);
             if (rc != STGCN_OK) return rc;
-            rc = launch_tcn(dz, packed, zeros, dx, N, Cout, Cin, Tout, V, K, 1, dfl | STGCN_RAW, st);
+            rc = launch_tcn(dz, packed, zeros, dx, N, Cout, Cin, Tz, V, K, 1, dfl | STGCN_RAW, st);
             if (rc != STGCN_OK) return rc;
         } else {
-            rc = launch_tcn_dgrad_valu(dz, W, dx, N, Cin, Cout, T, V, K, stride, Tout, st);
+            rc = launch_tcn_dgrad_valu(dz, W, dx, N, Cin, Cout, T, V, K, stride, Tz, st);
             if (rc != STGCN_OK) return rc;
         }
     } else if (tcn_dgrad_by_forward(K, stride)) {
         p += align_up((size_t)Cout * Cin * K * sizeof(float), 256) +
-             align_up(tcn_packed_bytes(Cout, Cin, K, tcn_dgrad_flags(Cin, Cout, Tout, V, K, flags)), 256);
+             align_up(tcn_packed_bytes(Cout, Cin, K, tcn_dgrad_flags(Cin, Cout, Tz, V, K, flags)), 256);
     }
     float *part = tcn_wgrad_ws_bytes(N, Cin, Cout, T, V, K, stride, flags) ? (float *)p : nullptr;
-    return launch_tcn_wgrad(dz, x, dW, part, N, Cin, Cout, T, V, K, stride, Tout, flags, st);
+    return launch_tcn_wgrad(dz, x, dW, part, N, Cin, Cout, T, V, K, stride, Tz, flags, st);
 }
 
 int stgcn_patch_embed(const float *z, const float *W, const float *b, const float *pos, float *out, int N, int C, int E,

@@ -170,6 +170,7 @@ int launch_bn_relu_bwd_stats(const float *za, const float *sa, const float *ta, 
                              const float *dy, double *sums, int N, int C, size_t plane, hipStream_t st);
 int launch_bn_bwd_finalize(const double *sums, int which, double count, const float *gamma, const float *invstd,
                            float *dgamma, float *dbeta, float *coef, int C, hipStream_t st, bool frozen = false);
+int launch_upsample2(const float *dz, float *dzu, size_t rows, int Tout, int T, int V, hipStream_t st);
 int launch_bn_relu_bwd_apply(const float *za, const float *sa, const float *ta, const float *ma, const float *ia,
                              const float *zb, const float *sb, const float *tb, const float *mb, const float *ib,
                              const float *dy, const float *coefa, const float *coefb, float *dza, float *dzb, double *bsum,

@@ -182,6 +182,15 @@ __global__ void doubles_to_floats_kernel(const double *__restrict__ src, float *
 // ------------------------------------------------------------------------------------------------------------------
 // dgrad, stride 1: dx = conv_t(dz, Wf) with Wf[c][o][k] = W[o][c][K-1-k]  -> the forward kernels do the contraction
 // ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample2_kernel(const float *__restrict__ dz, float *__restrict__ dzu, size_t total,
+                                                         int Tout, int T, int V) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const size_t row = e / ((size_t)T * V);
+    const int r = (int)(e - row * (size_t)T * V), t = r / V, v = r - t * V;
+    dzu[e] = ((t & 1) == 0 && (t >> 1) < Tout) ? dz[(row * Tout + (t >> 1)) * V + v] : 0.f;
+}
+
 __global__ void weight_flip_kernel(const float *__restrict__ W, float *__restrict__ Wf, int Cout, int Cin, int K) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= Cout * Cin * K) return;
@@ -570,6 +579,15 @@ int launch_bn_relu_bwd_apply(const float *za, const float *sa, const float *ta, 
 int launch_doubles_to_floats(const double *src, float *dst, int n, hipStream_t st) {
     hipLaunchKernelGGL(doubles_to_floats_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, src, dst, n);
     STGCN_LAUNCH_CHECK("doubles_to_floats_kernel");
+    return STGCN_OK;
+}
+
+// dzu[r][t][v] = dz[r][t/2][v] for even t < 2*Tout, 0 elsewhere (r = (clip, channel)): the stride-2 block's backward as the
+// stride-1 block's — dx = conv_t(dzu, flipped W), dW[k] = sum_t dzu[t] x[t+k-pad] — so that both run on the matrix cores
+int launch_upsample2(const float *dz, float *dzu, size_t rows, int Tout, int T, int V, hipStream_t st) {
+    const size_t total = rows * (size_t)T * V;
+    hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dz, dzu, total, Tout, T, V);
+    STGCN_LAUNCH_CHECK("upsample2_kernel");
     return STGCN_OK;
 }
 

@@ -679,7 +679,11 @@ def _kink_free_cotangent(y_ref, gen):
     (96, 128, 7, 1, 5, 8, 24, False),      # V = 24 (no padding), three 32-channel groups (one block per wave), K = 7, clips % splits != 0
     (64, 128, 3, 1, 2, 5, 20, True),       # K = 3, clip shorter than the ring's window
     (128, 64, 1, 1, 2, 6, 19, True),       # K = 1, 64 output channels (half the dz tile reads as zeros)
-    (64, 128, 9, 1, 1, 1, 22, True)])      # one clip of ONE frame: lead-in units only + a half-empty unit
+    (64, 128, 9, 1, 1, 1, 22, True),       # one clip of ONE frame: lead-in units only + a half-empty unit
+    # stride 2 with an odd K runs as the stride-1 backward on dz upsampled with zero frames (capi.hip: tcn_bwd_upsampled):
+    (64, 128, 3, 2, 2, 20, 22, True),      # even T (the last input frame gets no gradient term from a dz frame), K = 3
+    (128, 256, 9, 2, 2, 31, 25, False),    # odd T, 25 joints (the eight-wave wgrad kernel), no conv bias
+    (32, 64, 9, 2, 1, 2, 22, True)])       # two input frames -> one output frame
 def test_unit2d_backward_vs_oracle(cin, cout, K, stride, N, T, V, bias, math, dev):
     from stgcn_amd import Unit2D, set_math_mode
     from oracle import stgcn_oracle as so

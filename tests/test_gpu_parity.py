@@ -965,7 +965,8 @@ def test_generic_attention_on_matrix_cores_vs_oracle(cin, cout, N, T, V, layout,
     (128, 256, 1, 9, 25, True),     # wider, odd joint count
     (16, 32, 3, 7, 46, True),       # two-hand graph width, small channels (tiles mostly padding)
     (3, 128, 2, 20, 22, True),      # the stem's own shape WITH an input gradient: the generic chain, not the fused kernel
-    (64, 128, 2, 10, 22, False)])   # generic shape, x is data
+    (64, 128, 2, 10, 22, False),    # generic shape, x is data
+    (64, 64, 4, 90, 22, True)])     # long clips: the weight-gradient slices and joint Grams split along K (15 parts, the last EMPTY)
 def test_unit_agcn_generic_backward_vs_oracle(cin, cout, N, T, V, want_dx, dev):
     """unit_agcn backward for generic C_in / C_out, identity or conv residual, INCLUDING dx — what makes
     a TCN_GCN_unit (model/ST_TR/ST_TR_new.py:355-372) trainable.  Every gradient against autograd through the fp64
@@ -991,6 +992,14 @@ def test_unit_agcn_generic_backward_vs_oracle(cin, cout, N, T, V, want_dx, dev):
         _grad_gate(xg.grad, grads[-1], 1e-4, "dx")
     else:
         assert xg.grad is None
+    # fixed-order reductions (per-clip slices, K parts): a second run gives the same bits
+    first = {k: v.clone() for k, v in _agcn_module_grads(gcn).items()}
+    for p in gcn.parameters():
+        p.grad = None
+    y2 = gcn(x.to(dev).requires_grad_(want_dx))
+    (y2 * G.to(dev)).sum().backward()
+    for k, v in _agcn_module_grads(gcn).items():
+        assert torch.equal(v, first[k]), f"d{k}: the generic backward is not deterministic"
 
 
 def test_tcn_gcn_unit_trains_end_to_end(dev):

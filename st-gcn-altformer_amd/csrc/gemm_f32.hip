@@ -41,24 +41,44 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool a_k_fast = g.a_sk == 1;     // consecutive threads along the unit-stride index of each operand
     const bool b_n_fast = g.b_sn == 1 || g.b_sk != 1;
-    for (int k0 = k_lo; k0 < k_hi; k0 += GK) {
-        __syncthreads();
+    // the tile elements of this thread (GT*GK/256 = 4 of each operand), fetched one K chunk AHEAD into registers: the loads of
+    // chunk k0+GK are in flight while chunk k0 is multiplied (these products are small — the latency was all exposed)
+    constexpr int EPT = GT * GK / 256;
+    float ra[EPT], rb[EPT];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < GT * GK / 256; ++i) {
+        for (int i = 0; i < EPT; ++i) {
             const int e = tid + i * 256;
             const int m = a_k_fast ? e / GK : e % GT, k = a_k_fast ? e % GK : e / GT;
             const int gm = m0 + m, gk = k0 + k;
             const int q = g.m_inner ? gm / g.m_inner : gm, r = g.m_inner ? gm - q * g.m_inner : 0;
-            As[m * APAD + k] = (gm < g.M && gk < k_hi) ? A[(size_t)q * g.a_sm + (size_t)r * g.a_sm2 + (size_t)gk * g.a_sk] : 0.f;
+            ra[i] = (gm < g.M && gk < k_hi) ? A[(size_t)q * g.a_sm + (size_t)r * g.a_sm2 + (size_t)gk * g.a_sk] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < GT * GK / 256; ++i) {
+        for (int i = 0; i < EPT; ++i) {
             const int e = tid + i * 256;
             const int k = b_n_fast ? e / GT : e % GK, n = b_n_fast ? e % GT : e / GK;
             const int gk = k0 + k, gn = n0 + n;
-            Bs[k * BPAD + n] = (gk < k_hi && gn < g.N) ? B[(size_t)gk * g.b_sk + (size_t)gn * g.b_sn] : 0.f;
+            rb[i] = (gk < k_hi && gn < g.N) ? B[(size_t)gk * g.b_sk + (size_t)gn * g.b_sn] : 0.f;
+        }
+    };
+    if (k_lo < k_hi) fetch(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += GK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + i * 256;
+            const int m = a_k_fast ? e / GK : e % GT, k = a_k_fast ? e % GK : e / GT;
+            As[m * APAD + k] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + i * 256;
+            const int k = b_n_fast ? e / GT : e % GK, n = b_n_fast ? e % GT : e / GK;
+            Bs[k * BPAD + n] = rb[i];
         }
         __syncthreads();
+        if (k0 + GK < k_hi) fetch(k0 + GK);
         const float *ap = As + (wm * 32 + (lane & 31)) * APAD + (lane >> 5);
         const float *bp = Bs + (lane >> 5) * BPAD + wn * 32 + (lane & 31);
 #pragma unroll

@@ -11,12 +11,15 @@ independent, so ranks own disjoint shards and the data path has no collective; w
 with one tiny RCCL all-reduce of (clip count, output checksum sample) — the DP form of the reference's
 accuracy reduction (train_sttran.py:105-109).
 
-Two workloads:
-  default                weak scaling, --clips-per-gpu (256 = BASELINE configs[1]) clips on every rank;
-  --global-clips 8192    BASELINE configs[4]: ONE batch of 8192 clips sharded over the ranks
-                         (stgcn_amd.dist.shard_bounds), strong scaling; a rank walks its shard in sub-batches of
+Two workloads; the line's `value` is the one BASELINE.json quotes for that GPU count, the other kind is measured in the
+same process and reported beside it (`other_scaling`), so both scaling kinds are on every line:
+  N = 1 default          BASELINE configs[1]: --clips-per-gpu (256) clips, "scaling": "weak";
+  N > 1 default          BASELINE configs[4]: ONE batch of 8192 clips sharded over the ranks
+                         (stgcn_amd.dist.shard_bounds), "scaling": "strong"; a rank walks its shard in sub-batches of
                          at most --sub-batch clips (512: features + output of one sub-batch stay inside the
-                         256 MB Infinity Cache), so a step is ceil(shard / sub-batch) stem passes.
+                         256 MB Infinity Cache), so a step is ceil(shard / sub-batch) stem passes;
+  --weak                 force the weak-scaling workload at N > 1 (256 clips on every rank);
+  --global-clips G       force the strong-scaling workload with G clips (also at N = 1: 8192 = configs[4]'s base point).
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields:
   roofline      the dominant kernel, HIP-event timed on the launching stream over the timed region;
@@ -165,8 +168,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--clips-per-gpu", type=int, default=256, help="weak-scaling shard size; 256 = BASELINE configs[1]")
-    ap.add_argument("--global-clips", type=int, default=0,
-                    help="strong scaling: ONE batch of this many clips sharded over the ranks (8192 = BASELINE configs[4])")
+    ap.add_argument("--global-clips", type=int, default=None,
+                    help="strong scaling: ONE batch of this many clips sharded over the ranks (8192 = BASELINE configs[4]); "
+                         "default: 8192 when --gpus > 1 (the config BASELINE.json quotes for the scaling curve), weak at 1 GPU")
+    ap.add_argument("--weak", action="store_true", help="weak scaling (--clips-per-gpu on every rank) also at --gpus > 1")
+    ap.add_argument("--other-steps", type=int, default=10,
+                    help="timed steps of the block that measures the OTHER scaling kind in the same process (0 = skip)")
     ap.add_argument("--sub-batch", type=int, default=512, help="largest number of clips per stem pass in --global-clips mode")
     ap.add_argument("--frames", type=int, default=180)
     ap.add_argument("--graph", choices=["SHRE", "LMDHG"], default="SHRE")
@@ -184,7 +191,7 @@ def main():
     ap.add_argument("--cpu-clips", type=int, default=32)
     args = ap.parse_args()
     if args.no_extras:
-        args.steady_steps = args.alt_steps = args.train_steps = 0
+        args.steady_steps = args.alt_steps = args.train_steps = args.other_steps = 0
         args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -204,14 +211,11 @@ def main():
     sd.init(backend, dev)                                        # no-op at world 1
 
     T, V = args.frames, 22 if args.graph == "SHRE" else 46
+    if args.weak and args.global_clips:
+        raise SystemExit("--weak and --global-clips exclude each other")
+    if args.global_clips is None:
+        args.global_clips = 0 if (args.weak or world == 1) else 8192
     strong = args.global_clips > 0
-    if strong:
-        lo, hi = sd.shard_bounds(args.global_clips, rank, world)
-        n_local, n_global = hi - lo, args.global_clips
-        seed0 = 1000
-    else:
-        n_local, n_global = args.clips_per_gpu, args.clips_per_gpu * world
-        lo, seed0 = 0, rank
     gcn, tcn = build_stem(V, args.graph, args.math)
     cpu_state = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -220,32 +224,41 @@ def main():
     gcn, tcn = gcn.to(dev).eval(), tcn.to(dev).eval()
     if not args.no_fuse:
         stgcn_amd.enable_stem_fusion(gcn, tcn)
-
-    # this rank's clips, resident in HBM before any timing, cut into sub-batches (one, in the default workload)
-    sub = min(args.sub_batch, n_local) if strong else n_local
-    shard = []
-    for s in range(0, n_local, sub):
-        n = min(sub, n_local - s)
-        if strong:   # seeded by the sub-batch's position in the global batch
-            xs = synthetic_clips(n, T, V, seed=seed0 + (lo + s)).to(dev)
-        else:
-            xs = synthetic_clips(n, T, V, seed=seed0).to(dev)
-        if args.layout == "ntvc":
-            xs = xs.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)   # (N,T,V,3) in memory, viewed (N,3,T,V)
-        shard.append(xs)
     if args.layout == "ntvc":
         stgcn_amd.set_output_layout(tcn, "channels_last")
+
+    def make_workload(strong_, global_clips):
+        """This rank's clips, resident in HBM before any timing, cut into sub-batches (one, in the weak workload)."""
+        if strong_:
+            lo, hi = sd.shard_bounds(global_clips, rank, world)
+            n_loc, n_glob, seed0 = hi - lo, global_clips, 1000
+        else:
+            n_loc, n_glob, lo, seed0 = args.clips_per_gpu, args.clips_per_gpu * world, 0, rank
+        sub_ = min(args.sub_batch, n_loc) if strong_ else n_loc
+        pieces = []
+        for s_ in range(0, n_loc, max(sub_, 1)):
+            n = min(sub_, n_loc - s_)
+            # strong: seeded by the sub-batch's position in the global batch (the batch is the same at every world size)
+            xs = synthetic_clips(n, T, V, seed=seed0 + (lo + s_) if strong_ else seed0).to(dev)
+            if args.layout == "ntvc":
+                xs = xs.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)   # (N,T,V,3) in memory, viewed (N,3,T,V)
+            pieces.append(xs)
+        return {"strong": strong_, "shard": pieces, "n_local": n_loc, "n_global": n_glob, "sub": sub_}
+
+    wl = make_workload(strong, args.global_clips)
+    shard, n_local, n_global, sub = wl["shard"], wl["n_local"], wl["n_global"], wl["sub"]
     launches_per_step = len(shard)
     stats, pending = None, None
+    current = wl
 
     def step():
         nonlocal stats, pending
         out = None
         with torch.no_grad():
-            for xs in shard:
+            for xs in current["shard"]:
                 out = tcn(gcn(xs))
         if world > 1:   # tiny, latency-bound; RCCL over xGMI on its own stream, beside the next step's kernels
-            stats, pending = sd.all_reduce_stats_async(sd.step_stats(out, n_local))
+            stats, pending = sd.all_reduce_stats_async(sd.step_stats(out, current["n_local"]))
         return out
 
     def fence():
@@ -345,6 +358,29 @@ def main():
                                     "kernel_ms": None if k2 is None else round(k2, 4),
                                     "roofline_frac": None if not k2 else round(
                                         flops_clip * clips_per_launch / (k2 * 1e-3) / MFMA_PEAK[args.math], 4)}
+
+    # ---- the OTHER scaling kind, same process: strong (configs[4], 8192 clips over the ranks) beside a weak headline and
+    #      vice versa, so that every line carries both and the 1-GPU line holds the base point of the strong curve --------
+    if args.other_steps > 0 and T == 180 and V == 22:
+        ow = make_workload(not strong, 8192)
+        current = ow
+        eo, ko, no_, outo = timed_block(args.other_steps, 3)
+        assert torch.isfinite(outo).all()
+        if pending is not None:
+            pending.wait()
+        if stats is not None:
+            assert int(round(stats[0].item())) == ow["n_global"], "all-reduced clip count disagrees with the sharding"
+        current = wl
+        if rank == 0:
+            line["other_scaling"] = {
+                "scaling": "strong" if ow["strong"] else "weak",
+                "workload": (f"BASELINE configs[4]: ONE batch of {ow['n_global']} clips over {world} GPU(s), sub-batches <= {ow['sub']}"
+                             if ow["strong"] else f"{ow['n_local']} clips on every one of {world} GPU(s)"),
+                "global_clips": ow["n_global"], "clips_per_gpu": ow["n_local"], "stem_passes_per_step": len(ow["shard"]),
+                "steps": args.other_steps, "warmup": 3, "ms_per_step": round(eo / args.other_steps * 1e3, 4),
+                "value": round(ow["n_global"] * args.other_steps / eo, 1), "unit": "clips/s",
+                "kernel_ms": None if ko is None else round(ko, 4)}
+        del ow
 
     # ---- exact-fp32 arithmetic, same workload, short block -----------------------------------------------------
     if args.alt_steps > 0 and args.math != "f32":

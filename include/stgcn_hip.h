@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STGCN_ABI_VERSION 7
+#define STGCN_ABI_VERSION 8
 
 typedef enum {
     STGCN_OK = 0,
@@ -191,7 +191,10 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
 /* save_zm / save_zd (N,Cout,T,V): the two pre-BatchNorm branches (sum_s conv_d_s(x P_s), conv_down(x)) — asking for
  * them selects the materialising path; save_stats (STGCN_AGCN_SAVE_STATS_FLOATS(Cout) floats, 8-byte aligned): batch
  * mean, invstd of `bn`, then of the down BatchNorm (4*Cout), followed — on the moments path only — by the 63 feature
- * moments as doubles, which the stem-class backward reads back.  All optional (NULL). */
+ * moments as doubles, which the stem-class backward reads back, and a validity mark in one of the two spare floats
+ * behind them (ABI 8): the materialising path clears that block, and the moment-form backward answers NaN in every
+ * gradient when it is handed statistics without the mark (a forward that saved the branches, followed by a backward
+ * call with zm == NULL) instead of working from uninitialised moments.  All optional (NULL). */
 #define STGCN_AGCN_SAVE_STATS_FLOATS(Cout) (4 * (Cout) + 128)
 /* recompute: bit 0 = zm / zd are not supplied (the forward ran the moments path; the generic path rebuilds them in the
  * workspace, the stem-class path never needs them); bit 1 = size for the generic path — needed when an input gradient
@@ -262,13 +265,15 @@ int stgcn_patch_embed(const float *z, const float *W, const float *b, const floa
  * reference's accuracy reduction get_acc (SHREC/ST_TS/train_sttran.py:105-109: np.argmax of the
  * logits on the host, compared with the labels, summed): stats[0] = n_local, stats[1] = sum probe,
  * stats[2] = sum probe^2, stats[3] = #{n : argmax_c logits[n][c] == labels[n]}, with
- * probe[n][c] = out[n][c][0][0] (`plane` = T*V elements between consecutive (n,c) planes).
+ * probe[n][c] = out[n][c][0][0] = element n*clip_stride + c*chan_stride of `out` (ABI 8: element strides instead of a
+ * plane size, so the channels-last result of STGCN_OUT_NTVC — clip_stride = T*V*C, chan_stride = 1 — is probed in place;
+ * a dense (N,C,T,V) tensor has clip_stride = C*T*V, chan_stride = T*V).
  * logits (n_logits, classes) fp32 and labels (n_logits) int64 are optional (NULL: stats[3] = 0);
  * pred (n_logits) int64, optional, receives the class indices.  argmax follows numpy: the lowest
  * index among equal maxima, a NaN is the maximum.  `out` may be NULL when only the count is wanted.
  * One launch, one workgroup. */
-int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int C, long plane,
-                     float n_local, const float *logits, const long long *labels, long long *pred,
+int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int C, long clip_stride,
+                     long chan_stride, float n_local, const float *logits, const long long *labels, long long *pred,
                      int n_logits, int classes, void *stream);
 
 #ifdef __cplusplus

@@ -295,6 +295,12 @@ __global__ __launch_bounds__(256) void agcn_bwd_finalize_kernel(
     __shared__ double bS[256], cS[256];
     __shared__ float Wm[256 * SC];          // Wm[o][f] = Wd[f / 3][o][f % 3]: the R sums below read it 2 * Cout * 81 times
     const double *mu = mom, *muu = mom + SC, *mx = mom + SC + 45, *mxx = mom + SC + 45 + CIN;
+    // the moments are only there after a moments-path forward (agcn_train.hip marks them); after a materialising forward this
+    // block is uninitialised memory: every output of this kernel — and through rr everything downstream — becomes NaN
+    // instead of a plausible wrong gradient
+    const bool ok = reinterpret_cast<const unsigned *>(stats)[STGCN_MOMENTS_MARK_SLOT(Cout)] == STGCN_MOMENTS_MAGIC;
+    const double count_ = count;
+    count = ok ? count_ : __builtin_nan("");
     for (int e = threadIdx.x; e < Cout * SC; e += 256) {
         const int o = e / SC, f = e - o * SC;
         Wm[e] = Wd[((size_t)(f / CIN) * Cout + o) * CIN + (f % CIN)];
@@ -321,8 +327,8 @@ __global__ __launch_bounds__(256) void agcn_bwd_finalize_kernel(
             }
             const float db = (float)(am * Sg + count * (bm * zsum + cm));
             for (int s = 0; s < S; ++s) dbd[s * Cout + o] = db;          // every bd_s adds straight into zm
-            dgamma[o] = (float)dg;
-            dbeta[o] = (float)Sg;
+            dgamma[o] = (float)(dg + 0.0 * count);          // (0 * count: NaN without the moments mark)
+            dbeta[o] = (float)(Sg + 0.0 * count);
             bS[o] = bm;
             cS[o] = bm * bsum + cm;
         }
@@ -337,8 +343,8 @@ __global__ __launch_bounds__(256) void agcn_bwd_finalize_kernel(
                 dWdown[o * CIN + k] = (float)(ad * Gr[10 + k] + count * (bdd * zx + cd * mx[k]));
             }
             dbdown[o] = (float)(ad * Sg + count * (bdd * zsum + cd));
-            ddgamma[o] = (float)dg;
-            ddbeta[o] = (float)Sg;
+            ddgamma[o] = (float)(dg + 0.0 * count);
+            ddbeta[o] = (float)(Sg + 0.0 * count);
         }
     }
     __syncthreads();
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256) void agcn_bwd_finalize_kernel(
             }
         }
         a += __shfl_xor(a, 1, 64);
-        if (t < NRR && part == 0) rr[t] = (float)a;
+        if (t < NRR && part == 0) rr[t] = (float)(a + 0.0 * count);
     }
 }
 

@@ -136,6 +136,8 @@ __global__ __launch_bounds__(1024) void agcn_moments_finalize_kernel(
         mom[tid] = s / count;
         // the backward's moment form (agcn_backward.hip) reads the feature moments back: 63 doubles behind the 4*Cout floats
         if (save_stats) reinterpret_cast<double *>(save_stats + 4 * Cout)[tid] = mom[tid];
+        if (save_stats && tid == 0)   // validity mark for the moment-form backward (it used to trust the caller)
+            reinterpret_cast<unsigned *>(save_stats)[STGCN_MOMENTS_MARK_SLOT(Cout)] = STGCN_MOMENTS_MAGIC;
     }
     __syncthreads();
     const double *mu = mom, *muu = mom + SC, *mx = mom + SC + 45, *mxx = mom + SC + 45 + CIN;

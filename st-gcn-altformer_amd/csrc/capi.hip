@@ -57,17 +57,19 @@ __device__ inline int argmax_row(const float *__restrict__ row, int classes) {
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void step_stats_kernel(const void *__restrict__ out, float *__restrict__ stats,
-                                                          int NC, size_t plane, float n_local,
+                                                          int N, int C, size_t clip_stride, size_t chan_stride,
+                                                          float n_local,
                                                           const float *__restrict__ logits,
                                                           const long long *__restrict__ labels,
                                                           long long *__restrict__ pred, int n_logits, int classes) {
     __shared__ float red[3][4];
     float s1 = 0.f, s2 = 0.f, hit = 0.f;
     if (out != nullptr)
-        for (int e = threadIdx.x; e < NC; e += 256) {
+        for (int e = threadIdx.x; e < N * C; e += 256) {
+            const size_t at = (size_t)(e / C) * clip_stride + (size_t)(e % C) * chan_stride;   // element (n, c, 0, 0)
             float v;
-            if constexpr (BF16) v = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(out)[(size_t)e * plane] << 16);
-            else v = reinterpret_cast<const float *>(out)[(size_t)e * plane];
+            if constexpr (BF16) v = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(out)[at] << 16);
+            else v = reinterpret_cast<const float *>(out)[at];
             s1 += v;
             s2 = fmaf(v, v, s2);
         }
@@ -336,6 +338,8 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
     float *sv_mm = save_stats, *sv_im = save_stats ? save_stats + Cout : nullptr;
     float *sv_md = save_stats ? save_stats + 2 * Cout : nullptr, *sv_id = save_stats ? save_stats + 3 * Cout : nullptr;
     const size_t plane = (size_t)T * V, total = (size_t)N * Cout * plane;
+    if (save_stats)   // no feature moments on this path: clear their block incl. the validity mark the moment-form backward checks
+        STGCN_HIP_CHECK(hipMemsetAsync(save_stats + 4 * Cout, 0, 128 * sizeof(float), st));
     hipLaunchKernelGGL(fill_ones_zeros_kernel, dim3(ceil_div(Cout, 256)), dim3(256), 0, st, ones, zeros, Cout);
     STGCN_LAUNCH_CHECK("fill_ones_zeros_kernel");
     // main branch, pre-BN: sum_s conv_d_s(x P_s)   (unit scale on the main path, zero on the residual path, no ReLU)
@@ -673,11 +677,12 @@ int stgcn_patch_embed(const float *z, const float *W, const float *b, const floa
     return launch_patch_embed(z, W, b, pos, out, N, C, E, T, V, flags, (hipStream_t)stream);
 }
 
-int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int C, long plane, float n_local,
+int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int C, long clip_stride, long chan_stride,
+                     float n_local,
                      const float *logits, const long long *labels, long long *pred, int n_logits, int classes,
                      void *stream) {
     REQUIRE_PTR(stats);
-    if (out != nullptr) { REQUIRE_POS(N); REQUIRE_POS(C); REQUIRE_POS(plane); }
+    if (out != nullptr) { REQUIRE_POS(N); REQUIRE_POS(C); REQUIRE_POS(clip_stride); REQUIRE_POS(chan_stride); }
     if (logits != nullptr) {
         REQUIRE_POS(n_logits); REQUIRE_POS(classes);
         if (n_logits >= (1 << 24)) return fail(STGCN_ERR_UNSUPPORTED, "step_stats: %d rows of logits per call", n_logits);
@@ -686,11 +691,11 @@ int stgcn_step_stats(const void *out, int out_is_bf16, float *stats, int N, int 
     }
     if (out == nullptr && logits == nullptr) return fail(STGCN_ERR_ARG, "step_stats: neither out nor logits given");
     if (out_is_bf16)
-        hipLaunchKernelGGL(step_stats_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, out, stats, N * C,
-                           (size_t)plane, n_local, logits, labels, pred, n_logits, classes);
+        hipLaunchKernelGGL(step_stats_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, out, stats, N, C,
+                           (size_t)clip_stride, (size_t)chan_stride, n_local, logits, labels, pred, n_logits, classes);
     else
-        hipLaunchKernelGGL(step_stats_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)stream, out, stats, N * C,
-                           (size_t)plane, n_local, logits, labels, pred, n_logits, classes);
+        hipLaunchKernelGGL(step_stats_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)stream, out, stats, N, C,
+                           (size_t)clip_stride, (size_t)chan_stride, n_local, logits, labels, pred, n_logits, classes);
     STGCN_LAUNCH_CHECK("step_stats_kernel");
     return STGCN_OK;
 }

@@ -8,6 +8,11 @@
 
 #include "../../include/stgcn_hip.h"
 
+// save_stats[4*Cout + 126] (one of the two spare floats behind the 63 moment doubles): written by the moments-path forward,
+// cleared by the materialising path, checked by the moment-form backward (which poisons its outputs with NaN without it).
+#define STGCN_MOMENTS_MAGIC 0x4D4F4D31u   /* "MOM1" */
+#define STGCN_MOMENTS_MARK_SLOT(Cout) (4 * (Cout) + 126)
+
 namespace stgcn {
 
 constexpr int kWave = 64;          // CDNA wavefront

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STGCN_LIB") or os.path.join(_HERE, "libstgcn_hip.so")   # STGCN_LIB: diagnostic builds
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # stgcn_math / flags (include/stgcn_hip.h)
 MATH_F32 = 0
@@ -53,7 +53,7 @@ PROTOTYPES = {
     "stgcn_stem_tail_prepared": (c_int, [_P] * 2 + [c_size_t] + [_P] * 3 + [c_int] * 7 + [c_uint, _P]),
     "stgcn_stem_forward_prepared": (c_int, [_P] * 9 + [c_size_t] + [_P] + [c_int] * 8 + [c_uint, _P]),
     "stgcn_patch_embed": (c_int, [_P] * 5 + [c_int] * 5 + [c_uint, _P]),
-    "stgcn_step_stats": (c_int, [_P, c_int, _P, c_int, c_int, c_long, c_float, _P, _P, _P, c_int, c_int, _P]),
+    "stgcn_step_stats": (c_int, [_P, c_int, _P, c_int, c_int, c_long, c_long, c_float, _P, _P, _P, c_int, c_int, _P]),
     "stgcn_agcn_train_ws_bytes": (c_size_t, [c_int] * 7),
     "stgcn_agcn_forward_train": (c_int, [_P] * 18 + [c_float, c_float, _P, _P, c_size_t] + [_P] * 4 + [c_int] * 7 + [c_uint, _P]),
     "stgcn_agcn_backward_ws_bytes": (c_size_t, [c_int] * 7),

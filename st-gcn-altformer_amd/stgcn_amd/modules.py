@@ -6,8 +6,8 @@ initialisation and error behaviour.  ``forward`` hands raw device pointers to th
 there is no torch-op implementation of the math in this package.
 
 Eval-mode parameters are folded/packed once and cached; the cache is keyed on the version
-counters of every parameter and buffer, so an optimizer step, ``load_state_dict`` or a manual
-in-place edit invalidates it automatically.
+counter AND the storage address of every parameter and buffer, so an optimizer step,
+``load_state_dict``, a manual in-place edit or a ``param.data = other`` swap invalidates it.
 """
 from __future__ import annotations
 
@@ -39,7 +39,10 @@ def _identity(x):
 
 
 def _versions(mod: nn.Module):
-    return tuple(t._version for t in list(mod.parameters()) + list(mod.buffers()))
+    """Cache key over every parameter and buffer: (version counter, storage address).  The counter sees in-place edits
+    (an optimizer step, load_state_dict, ``p.data.mul_()``); the address sees ``param.data = new_tensor`` — an EMA or
+    weight swap done that way leaves ``_version`` where it was (round-2 review) but moves ``data_ptr()``."""
+    return tuple((t._version, t.data_ptr()) for t in list(mod.parameters()) + list(mod.buffers()))
 
 
 def _wants_grad(mod: nn.Module, x: torch.Tensor) -> bool:
@@ -292,7 +295,7 @@ class unit_agcn(nn.Module):
 
     def _staged(self, device):
         """Stacked / folded device tensors for the C ABI, cached until any parameter changes."""
-        key = (device, _versions(self), self.A._version, id(self.A))
+        key = (device, _versions(self), self.A._version, id(self.A), self.A.data_ptr())
         if self._cache is not None and self._cache["key"] == key:
             return self._cache
         with torch.no_grad():
@@ -324,7 +327,7 @@ class unit_agcn(nn.Module):
             # A = self.A.cuda(dev) + self.PA  (model/unit_agcn.py:75-76).  The constant A is uploaded once per device and
             # version — not per call, and not per restage either: in training every step restages (PA moved), and a
             # host-to-device copy there would synchronise the host each step and forbid capturing the step in a HIP graph
-            akey = (device, self.A._version, id(self.A))
+            akey = (device, self.A._version, id(self.A), self.A.data_ptr())
             if getattr(self, "_A_dev_key", None) != akey:
                 object.__setattr__(self, "_A_dev", self.A.to(device=device, dtype=torch.float32).contiguous())
                 object.__setattr__(self, "_A_dev_key", akey)

@@ -158,7 +158,9 @@ def _reducer_worker(rank, world, port, mode, q):
                               torch.nn.Conv2d(16, 16, (3, 1), padding=(1, 0)), torch.nn.ReLU(),
                               torch.nn.Conv2d(16, 4, 1))
     unused = torch.nn.Linear(5, 5)                          # never in the graph: its slots must travel as zeros
-    red = sd.GradReducer([net, unused], bucket_bytes=2048, mode=mode)
+    # (listed first = last in bucket order: buckets are issued strictly in order, so a never-ready bucket holds back the
+    #  ones behind it until finish() — in front of the used ones it would cost the whole overlap)
+    red = sd.GradReducer([unused, net], bucket_bytes=2048, mode=mode)
     fired = []
     for step in range(2):
         x = torch.randn(4, 3, 6, 5, generator=torch.Generator().manual_seed(100 * step + rank))
@@ -203,3 +205,139 @@ def test_two_rank_grad_reducer_overlapped_buckets(mode):
             assert torch.allclose(torch.from_numpy(got), w, rtol=1e-5, atol=1e-7)
         for got in grads[len(want):]:
             assert not got.any()                      # the unused module: zeros in, zeros out
+
+
+def _stale_worker(rank, world, port, unused_mode, q):
+    """ADVICE r2 / VERDICT r2 #11: a parameter used in step 0 and skipped in steps 1 and 2 under set_to_none must travel as
+    zeros (or end as None), never as the previous step's averaged gradient."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, "st-gcn-altformer_amd"))
+    torch.set_num_threads(1)
+    from stgcn_amd import dist as sd
+    sd.init("gloo")
+    torch.manual_seed(3)
+    a, b = torch.nn.Linear(6, 6), torch.nn.Linear(6, 6)
+    red = sd.GradReducer([a, b], bucket_bytes=64, unused=unused_mode)
+    x = torch.randn(5, 6, generator=torch.Generator().manual_seed(50 + rank))
+    log = []
+    for step in range(3):
+        for p in list(a.parameters()) + list(b.parameters()):
+            p.grad = None                                         # optimizer.zero_grad(set_to_none=True)
+        # step 0: a and b; steps 1, 2: a only — on rank 0.  Rank 1 uses b in step 1 as well (unused on ONE rank only).
+        use_b = step == 0 or (step == 1 and rank == 1)
+        y = a(x)
+        if use_b:
+            y = b(y)
+        y.square().mean().backward()
+        red.finish()
+        log.append([None if p.grad is None else p.grad.clone().numpy() for p in b.parameters()])
+    q.put((rank, log))
+    red.remove()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("unused_mode", ["zeros", "none"])
+def test_grad_reducer_unused_parameter_two_steps_running(unused_mode):
+    res = _run_two(_stale_worker, unused_mode)
+    # independent single-process gradients of b per rank and step
+    torch.manual_seed(3)
+    a, b = torch.nn.Linear(6, 6), torch.nn.Linear(6, 6)
+    def grad_b(rank):
+        for p in list(a.parameters()) + list(b.parameters()):
+            p.grad = None
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(50 + rank))
+        b(a(x)).square().mean().backward()
+        return [p.grad.clone() for p in b.parameters()]
+    g0, g1 = grad_b(0), grad_b(1)
+    for rank, log in res:
+        for got, w0, w1 in zip(log[0], g0, g1):                   # step 0: mean of both ranks
+            assert torch.allclose(torch.from_numpy(got), (w0 + w1) / 2, rtol=1e-5, atol=1e-7)
+        for got, w1 in zip(log[1], g1):                           # step 1: rank 0 skipped b -> zeros + rank 1's, averaged
+            assert torch.allclose(torch.from_numpy(got), w1 / 2, rtol=1e-5, atol=1e-7)
+        for got in log[2]:                                        # step 2: nobody used b
+            if unused_mode == "none":
+                assert got is None                                # as under the reference's DataParallel
+            else:
+                assert got is not None and not got.any()          # zeros — NOT step 1's averaged gradient
+
+
+def _accum_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, "st-gcn-altformer_amd"))
+    torch.set_num_threads(1)
+    from stgcn_amd import dist as sd
+    sd.init("gloo")
+    torch.manual_seed(9)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Tanh(), torch.nn.Linear(8, 2))
+    red = sd.GradReducer(net, bucket_bytes=64)
+    xs = [torch.randn(3, 4, generator=torch.Generator().manual_seed(10 * k + rank)) for k in range(2)]
+    red.zero_grad()
+    with red.no_sync():                                           # micro-batch 0: accumulate only
+        net(xs[0]).square().mean().backward()
+        assert not any(b["launched"] for b in red.buckets)
+    net(xs[1]).square().mean().backward()                        # micro-batch 1: buckets go out from the hooks
+    red.finish()
+    grads = [p.grad.clone().numpy() for p in net.parameters()]
+    # two backward() calls WITHOUT no_sync: the second would write into a bucket that is on the wire -> loud error
+    red.zero_grad()
+    net(xs[0]).square().mean().backward()
+    try:
+        net(xs[1]).square().mean().backward()
+        raised = False
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    red.finish()                                                  # drain what is in flight before leaving
+    q.put((rank, grads, raised))
+    red.remove()
+    torch.distributed.destroy_process_group()
+
+
+def test_grad_reducer_accumulation_and_double_backward_guard():
+    res = _run_two(_accum_worker)
+    torch.manual_seed(9)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Tanh(), torch.nn.Linear(8, 2))
+    want = None
+    for rank in range(2):
+        net.zero_grad()
+        for k in range(2):
+            x = torch.randn(3, 4, generator=torch.Generator().manual_seed(10 * k + rank))
+            net(x).square().mean().backward()                     # torch accumulates both micro-batches
+        g = [p.grad.clone() for p in net.parameters()]
+        want = g if want is None else [u + v for u, v in zip(want, g)]
+    want = [w / 2 for w in want]
+    for rank, grads, raised in res:
+        assert raised
+        for got, w in zip(grads, want):
+            assert torch.allclose(torch.from_numpy(got), w, rtol=1e-5, atol=1e-7)
+
+
+def _none_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, "st-gcn-altformer_amd"))
+    torch.set_num_threads(1)
+    from stgcn_amd import dist as sd
+    sd.init("gloo")
+    torch.manual_seed(2)
+    used, never = torch.nn.Linear(3, 3), torch.nn.Linear(3, 3)
+    used(torch.ones(2, 3) * (rank + 1)).sum().backward()
+    if rank == 0:
+        used.bias.grad = None                                     # missing on one rank: zero-filled, stays a tensor
+    n = sd.all_reduce_grads([used, never])
+    none_first = [p.grad is None for p in never.parameters()]
+    bias_first = used.bias.grad.clone().numpy()
+    n2 = sd.all_reduce_grads([used, never], keep_none=False)      # second call: `never` now receives zeros
+    q.put((rank, n, n2, bias_first, [p.grad is None for p in never.parameters()], none_first,
+           [float(p.grad.abs().sum()) for p in never.parameters()]))
+    torch.distributed.destroy_process_group()
+
+
+def test_all_reduce_grads_keeps_globally_missing_gradients_none():
+    """a parameter without a gradient on ANY rank keeps .grad None (the optimizer skips it, as under the
+    reference's DataParallel); keep_none=False restores the zeros."""
+    res = _run_two(_none_worker)
+    for rank, n, n2, bias_first, none_after, none_first, zsum in res:
+        assert n == n2 == 2 * (9 + 3)
+        assert none_first == [True, True]                         # None on every rank: left None
+        assert none_after == [False, False] and zsum == [0.0, 0.0]   # keep_none=False: zeros
+        # bias of `used`: None on rank 0 -> counts as zeros; rank 1 has 2 per element (batch of 2); mean = 1
+        assert bias_first.tolist() == [1.0, 1.0, 1.0]

@@ -1361,3 +1361,91 @@ def test_stem_backward_moment_form_matches_gemm_chain_at_size(N, T, V, cout, dev
         if err > 2e-4 * max(scale, 1e-30):
             bad.append(f"{k}: {err:.3e} vs 2e-4*{scale:.3e}")
     assert not bad, "; ".join(bad)
+
+
+# ---------------------------------------------------------------------------------------
+# round 3: host-side hardening
+# ---------------------------------------------------------------------------------------
+def test_step_stats_probes_the_channels_last_result_in_place(dev):
+    """`bench.py --layout ntvc --gpus N>1` calls step_stats on the (N,C,T,V) VIEW of (N,T,V,C) memory that the
+    fused stem returns under set_output_layout('channels_last'); it used to be refused (non-contiguous)."""
+    from stgcn_amd import dist as sd, enable_stem_fusion, set_output_layout
+    gcn, tcn, gp, tp, gen = _random_stem(22, None, 31, dev)
+    enable_stem_fusion(gcn, tcn)
+    x = torch.randn(5, 3, 40, 22, generator=gen).to(dev)
+    with torch.no_grad():
+        ref = tcn(gcn(x))
+        set_output_layout(tcn, "channels_last")
+        out = tcn(gcn(x))
+    assert not out.is_contiguous() and out.permute(0, 2, 3, 1).is_contiguous()
+    assert torch.equal(out, ref)
+    got, want = sd.step_stats(out, 5).cpu(), sd.step_stats(ref, 5).cpu()
+    assert torch.equal(got, want)                                   # same 5 x 128 probes, same summation order
+    probe = ref[:, :, 0, 0].double().cpu()
+    assert torch.allclose(got.double(), torch.tensor([5.0, probe.sum().item(), probe.square().sum().item(), 0.0],
+                                                     dtype=torch.float64), rtol=1e-5, atol=1e-3)
+    sliced = ref[:, ::2]                                            # any positive clip / channel strides
+    p2 = sliced[:, :, 0, 0].double().cpu()
+    assert torch.allclose(sd.step_stats(sliced, 5).cpu()[1:3].double(),
+                          torch.tensor([p2.sum().item(), p2.square().sum().item()], dtype=torch.float64), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_parameter_swap_by_data_assignment_restages(fused, dev):
+    """``param.data = new`` (an EMA / weight swap) does not bump ``_version``; the staging cache is keyed
+    on the storage address as well, so the next forward uses the new values (checked against the oracle)."""
+    from stgcn_amd import enable_stem_fusion
+    from oracle import stgcn_oracle as so
+    gcn, tcn, gp, tp, gen = _random_stem(22, None, 77, dev)
+    if fused:
+        enable_stem_fusion(gcn, tcn)
+    x = torch.randn(2, 3, 24, 22, generator=gen)
+    with torch.no_grad():
+        z0 = tcn(gcn(x.to(dev))).cpu()
+        parity_gate(z0, so.stem_forward(x, gp, tp), 1e-4, "before the swap")
+        v = (tcn.conv.weight._version, gcn.PA._version, gcn.bn.running_var._version)
+        tcn.conv.weight.data = (torch.randn(tcn.conv.weight.shape, generator=gen) * 0.05).to(dev)
+        gcn.PA.data = (torch.randn(3, 22, 22, generator=gen) * 0.1).to(dev)
+        gcn.conv_d[1].weight.data = (torch.randn(gcn.conv_d[1].weight.shape, generator=gen) * 0.3).to(dev)
+        gcn.bn.running_var.data = (torch.rand(128, generator=gen) + 0.5).to(dev)     # a buffer, swapped the same way
+        assert v == (tcn.conv.weight._version, gcn.PA._version, gcn.bn.running_var._version)   # the premise of the test
+        z1 = tcn(gcn(x.to(dev))).cpu()
+    gcn_cpu = {k: t.detach().cpu() for k, t in gcn.state_dict().items()}
+    tcn_cpu = {k: t.detach().cpu() for k, t in tcn.state_dict().items()}
+    ref = so.stem_forward(x, so.agcn_params_from_state(gcn_cpu, gcn.A), so.tcn_params_from_state(tcn_cpu))
+    parity_gate(z1, ref, 1e-4, "after the swap")
+    assert (z1 - z0).abs().max() > 1e-2 * ref.abs().max()           # the swap is visible at all
+
+
+def test_moment_form_backward_refuses_statistics_without_moments(dev):
+    """stgcn_agcn_backward_train picks the moment form from (zm == NULL, y != NULL, no dx) and then reads the 63
+    feature moments behind save_stats — which only a moments-path forward writes.  A forward that saved the branches now
+    clears that block (validity mark), and the moment form answers NaN everywhere instead of a plausible wrong gradient;
+    the properly paired calls are unaffected."""
+    from stgcn_amd import functional as F
+    gcn, tcn, gp, tp, gen = _random_stem(22, None, 13, dev)
+    gcn.train()
+    st = gcn._staged(dev)
+    x = torch.randn(3, 3, 20, 22, generator=gen).to(dev)
+    dy = torch.randn(3, 128, 20, 22, generator=gen).to(dev)
+    bn, d = gcn.bn, gcn.down[1]
+    def fwd(save):
+        return F.agcn_forward_train(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"],
+                                    st["bdown"], (bn.weight.detach(), bn.bias.detach(), bn.running_mean.clone(), bn.running_var.clone()),
+                                    (d.weight.detach(), d.bias.detach(), d.running_mean.clone(), d.running_var.clone()),
+                                    bn.momentum, bn.eps, save=save)
+    def bwd(P, zm, zd, stats, y):
+        return F.agcn_backward_train(x, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"],
+                                     st["bdown"], P, zm, zd, bn.weight.detach(), bn.bias.detach(), d.weight.detach(),
+                                     d.bias.detach(), stats, dy, need_dx=False, y=y)
+    y1, P1, zm1, zd1, stats1 = fwd(True)               # moments path
+    y2, P2, zm2, zd2, stats2 = fwd("branches")         # materialising path: branches saved, no moments
+    assert zm1 is None and zm2 is not None
+    parity_gate(y2, y1, 1e-5, "both forwards agree")
+    good = bwd(P1, None, None, stats1, y1)             # moment form, properly paired
+    chain = bwd(P2, zm2, zd2, stats2, y2)              # GEMM chain on the saved branches
+    for k in ("dWd", "dWdown", "dgamma", "dbeta", "ddgamma", "dPA", "dWa", "dWb"):
+        parity_gate(good[k], chain[k], 2e-4, f"moment form vs GEMM chain: {k}", strict=False)
+    bad = bwd(P2, None, None, stats2, y2)              # the mis-paired call of the advisor's report
+    for k in ("dWd", "dbd", "dWdown", "dbdown", "dgamma", "dbeta", "ddgamma", "ddbeta", "dPA", "dWa", "dWb"):
+        assert torch.isnan(bad[k]).all(), f"{k}: a mis-paired moment-form backward must not return numbers"

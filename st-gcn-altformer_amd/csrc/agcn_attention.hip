@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * NW) void attention_folded_kernel(
     const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
     float *__restrict__ P, float *__restrict__ feat, uint4 *__restrict__ pfrag, int Cin, int T, int V, int inter_c,
     int S, int TC, int Rp, int feat_slice_off, int sq_behind, int xsc, int xsp, float *__restrict__ xcopy,
-    unsigned long long *dbg) {
+    unsigned long long *dbg, int pf_v0) {
     // x element (channel k, pixel p) of a clip sits at k*xsc + p*xsp: (T*V, 1) for (N,Cin,T,V), (1, Cin) for (N,T,V,Cin).
     // xcopy (optional): channel-major copy of x for kernels downstream that read it in that layout.
 #ifdef STGCN_ABLATION  // in-kernel cycle stamps (diagnostic builds only)
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64 * NW) void attention_folded_kernel(
     // (4 frames x 4 channels) x 32 x 16 product per v_mfma_f32_16x16x32_bf16, B[v][w'] = P_s[v][16h + w'].  Fragment
     // f = (s*2 + h)*2 + (0: bf16 hi, 1: lo residual), lane l holds v = 8*(l>>4) .. +7 of column w = 16h + (l&15); zeros
     // past V.  12 KiB per clip instead of 64 B per pixel (253 KiB at T=180, V=22).
-    if (pfrag != nullptr) {                    // (host side guarantees S == 3, V <= 32)
+    if (pfrag != nullptr && pf_v0 == 0) {      // (host side guarantees S == 3, V <= 32)
         uint4 *pf = pfrag + (size_t)n * 12 * 64;
         for (int e = tid; e < 6 * 64; e += NTH) {
             const int sh = e >> 6, l = e & 63, s = sh >> 1, h = sh & 1;
@@ -270,6 +270,27 @@ __global__ __launch_bounds__(64 * NW) void attention_folded_kernel(
             bf16k::split8(pv, hi, lo);
             pf[(sh * 2 + 0) * 64 + l] = hi;
             pf[(sh * 2 + 1) * 64 + l] = lo;
+        }
+    }
+    // Wide frames (32 < V <= 64, the two-hand graph): the fused kernel splits the JOINT axis in two column halves —
+    // joints [0, V0) and [V0, V) — that it treats as two narrow clips (the temporal conv never mixes joints), while the
+    // aggregation still sums over all V joints: two k-steps of 32.  Fragment ((((half*3 + s)*2 + h)*2 + ks)*2 + img):
+    // lane l holds v = 32*ks + 8*(l>>4) .. +7 of column w = j0(half) + 16h + (l&15); zeros past V / past the half.
+    // 48 KiB per clip.
+    if (pfrag != nullptr && pf_v0 > 0) {
+        uint4 *pf = pfrag + (size_t)n * 48 * 64;
+        for (int e = tid; e < 24 * 64; e += NTH) {
+            const int f = e >> 6, l = e & 63;                      // f = ((half*3 + s)*2 + h)*2 + ks
+            const int ks = f & 1, h = (f >> 1) & 1, hs = f >> 2, s = hs % 3, half = hs / 3;
+            const int j0 = half ? pf_v0 : 0, vh = half ? V - pf_v0 : pf_v0;
+            const int wl = 16 * h + (l & 15), w = j0 + wl, v0 = 32 * ks + 8 * (l >> 4);
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = (wl < vh && v0 + j < V) ? Sm[(s * V + v0 + j) * V + w] : 0.f;
+            uint4 hi, lo;
+            bf16k::split8(pv, hi, lo);
+            pf[(f * 2 + 0) * 64 + l] = hi;
+            pf[(f * 2 + 1) * 64 + l] = lo;
         }
     }
     if (feat == nullptr) return;
@@ -631,10 +652,12 @@ bool attention_emits_features(int Cin, int V, int S) {
 
 int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
                      const float *Wb, const float *bb, float *P, float *feat, int N, int Cin, int T, int V,
-                     int inter_c, int S, hipStream_t st, bool x_ntvc, float *xcopy, void *pfrag) {
+                     int inter_c, int S, hipStream_t st, bool x_ntvc, float *xcopy, void *pfrag, int pf_v0) {
     const int xsc = x_ntvc ? 1 : T * V, xsp = x_ntvc ? Cin : 1;
-    if (pfrag != nullptr && (Cin != 3 || S != 3 || V > 32 || feat != nullptr))
+    if (pfrag != nullptr && (Cin != 3 || S != 3 || (pf_v0 == 0 && V > 32) || feat != nullptr))
         return fail(STGCN_ERR_UNSUPPORTED, "attention: fragment output covers Cin=3, 3 subsets, V<=32 (got %d, %d, %d)", Cin, S, V);
+    if (pfrag != nullptr && pf_v0 != 0 && (pf_v0 < 1 || pf_v0 > 32 || V - pf_v0 < 1 || V - pf_v0 > 32))
+        return fail(STGCN_ERR_UNSUPPORTED, "attention: joint split %d | %d outside 1..32 per half", pf_v0, V - pf_v0);
     if (feat != nullptr && (Cin != 3 || S != 3))
         return fail(STGCN_ERR_UNSUPPORTED, "attention: the feature pass covers Cin=3, 3 subsets (got %d, %d)", Cin, S);
     const FoldedPlan pl = plan_folded(Cin, T, V, inter_c, S, feat != nullptr);
@@ -648,7 +671,7 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
     do {                                                                                               \
         STGCN_HIP_CHECK(allow_lds((attention_folded_kernel<MI, TSL>), lds));                           \
         hipLaunchKernelGGL((attention_folded_kernel<MI, TSL>), dim3(N), dim3(64 * TSL), lds, st, x, A_eff, \
-                           Wa, ba, Wb, bb, P, feat, (uint4 *)pfrag, Cin, T, V, inter_c, S, TC, Rp, slice_off, pl.sq_behind, xsc, xsp, xcopy, debug_buffer()); \
+                           Wa, ba, Wb, bb, P, feat, (uint4 *)pfrag, Cin, T, V, inter_c, S, TC, Rp, slice_off, pl.sq_behind, xsc, xsp, xcopy, debug_buffer(), pf_v0); \
     } while (0)
         if (pl.nw == 16) {
             if (pl.maxb <= 1) LAUNCH_FOLDED(1, 16);

@@ -101,7 +101,8 @@ int launch_bn_fold(const float *w, const float *b, const float *rm, const float 
 int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
                      const float *Wb, const float *bb, float *P, float *feat, int N, int Cin, int T,
                      int V, int inter_c, int S, hipStream_t st, bool x_ntvc = false, float *xcopy = nullptr,
-                     void *pfrag = nullptr);   // pfrag: (N,12,64) x 16 B attention B-fragments instead of features
+                     void *pfrag = nullptr,    // pfrag: (N,12,64) x 16 B attention B-fragments instead of features
+                     int pf_v0 = 0);           // > 0: wide frames, (N,48,64) x 16 B fragments for the joint split V0 | V - V0
 
 int launch_agcn_expand(const float *x, const float *P, const float *Wd, const float *bd,
                        const float *Wdown, const float *bdown, const float *bn_scale,
@@ -140,6 +141,16 @@ int launch_stem_v4(const float *x, bool x_ntvc, const float *feat, const void *p
 // channels of 64 pixels); reads the temporal weights in its own pair order, which stgcn_stem_prepare appends to the prep
 // blob behind the 32x32x16 packing
 bool stem_v6_supported(int C, int T, int V, int K, unsigned flags);
+// ... and for wide frames (32 < V <= 64, V even: the two-hand graph) the same kernel over the two joint halves [0, V0) and
+// [V0, V), each handled like a narrow clip (stem_bf16_v6w.hip); the attention kernel then emits 48 fragments per clip
+static inline int stem_wide_split(int V) {     // V0 (a multiple of 4: 16-byte aligned half rows), or 0 when V does not split
+    if (V <= 32 || V > 64 || (V & 1)) return 0;
+    const int v0 = (V / 2 + 3) / 4 * 4;
+    return (v0 <= 32 && V - v0 >= 1) ? v0 : 0;
+}
+bool stem_v6w_supported(int C, int T, int V, int K, unsigned flags);
+int launch_stem_v6w(const float *x, bool x_ntvc, const void *pfrag, const void *prep_w12, const void *Wq, const float *shift,
+                    void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st);
 int launch_tcn_pack_bf16_pairs(const float *W, const float *scale, void *Wq, int Cin, int Cout, hipStream_t st);
 int launch_stem_v6(const float *x, bool x_ntvc, const void *pfrag, const void *prep_w12, const void *Wq, const float *shift,
                    void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st);

@@ -907,8 +907,10 @@ bool stem_v4_supported(int Cin, int C, int T, int V, int K, int S, unsigned flag
 bool stem_v4_features_in_kernel(int C, int T, int V, int K, unsigned flags) {
     const unsigned math = flags & STGCN_MATH_MASK;
     V4Plan pl;
-    return (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) && plan_v4(C, T, V, K, math == STGCN_MATH_BF16X3 ? 3 : 1, pl) &&
-           pl.nj == 2;
+    if (!((math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) && plan_v4(C, T, V, K, math == STGCN_MATH_BF16X3 ? 3 : 1, pl)))
+        return false;
+    // the 256-pixel tile, or — wide frames — KF6 over the two joint halves (diagnostic builds: mask bit 256 keeps KF4)
+    return pl.nj == 2 || (stem_v6w_supported(C, T, V, K, flags) && !(ablate_mask() & 256));
 }
 
 int launch_stem_v4(const float *x, bool x_ntvc, const float *feat, const void *prep_w12, const void *Wp, const float *shift,
@@ -928,6 +930,10 @@ int launch_stem_v4(const float *x, bool x_ntvc, const float *feat, const void *p
     if (pl.nj == 2 && stem_v6_supported(C, T, V, K, flags) && !(ablate_mask() & 256))
         return launch_stem_v6(x, x_ntvc, feat, prep_w12, (const char *)Wp + tcn_packed_single_bytes(C, C, K, flags), shift, out, N, C, T,
                               V, K, flags, st);
+    // wide frames (the two-hand graph): the same one-wave-per-SIMD kernel over the two joint halves (stem_bf16_v6w.hip)
+    if (pl.nj == 1 && stem_v6w_supported(C, T, V, K, flags) && !(ablate_mask() & 256))
+        return launch_stem_v6w(x, x_ntvc, feat, prep_w12, (const char *)Wp + tcn_packed_single_bytes(C, C, K, flags), shift, out, N, C,
+                               T, V, K, flags, st);
     const float4 *f4 = (const float4 *)feat;
     const float *W12 = (const float *)prep_w12;
     const uint4 *wp = (const uint4 *)Wp;

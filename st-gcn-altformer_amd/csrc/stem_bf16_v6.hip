@@ -31,9 +31,24 @@
 // block's weight fragments in registers (read one block ahead of use).
 // Per-tile tail: epilogue staged 16 channels x 64 pixels at a time through LDS (16-byte stores, scalar base + one per-lane
 // term), next tile's x loads in flight during the stores, feature phase, chunk-0 production.
+//
+// WIDE (stem_bf16_v6w.hip compiles this file with STGCN_V6_WIDE): frames of 32 < V <= 64 joints (the two-hand graph, V = 46).
+// The temporal conv never mixes joints, so the joint axis is cut into two halves [0, V0) and [V0, V) (V0 a multiple of 4,
+// both halves <= 32 joints) and each (clip, half) is walked like a narrow clip of Vh joints: same tile, images, producer
+// and main loop.  What differs sits in the per-tile tail only: the aggregation u_s = x P_s sums over ALL V joints (two
+// k-steps of 32 per feature MFMA; 24 attention fragments per half, which live in the idle second image buffer between
+// the main loops instead of a region of their own), and the epilogue maps a half-space pixel (t, v') to the clip's
+// (t, j0 + v'): pairs of pixels stay 8-byte aligned (V, V0 even), so rows go out as 8-byte stores.
+// The two instantiations live in separate translation units so that neither perturbs the other's code generation.
 #include <type_traits>
 
 #include "bf16_common.h"
+
+#ifdef STGCN_V6_WIDE
+#define V6W true
+#else
+#define V6W false
+#endif
 
 namespace stgcn {
 
@@ -80,6 +95,7 @@ __device__ __forceinline__ void static_for6(F &&f) {
     }
 }
 
+#ifndef STGCN_V6_WIDE
 // weight packing for KF6: Wq (bf16) index ((((ob*npairs + q)*2 + img)*64 + lane)*8 + j
 //   o = ob*16 + (lane&15); step f = 2q + (lane>>5); chunk f/9, tap f%9; c = chunk*16 + 8*((lane>>4)&1) + j
 __global__ void tcn_pack_bf16_pairs_kernel(const float *__restrict__ W, const float *__restrict__ scale,
@@ -102,12 +118,19 @@ __global__ void tcn_pack_bf16_pairs_kernel(const float *__restrict__ W, const fl
     const unsigned l = pack_bf16x2(w - bf16_lo_to_f32(h), 0.f) & 0xffffu;
     Wq[e] = (unsigned short)(img ? l : h);
 }
+#endif
 
-template <int TERMS, bool BF16OUT>
+struct TileInfo6 {
+    int n, Vh, j0, half;
+    TileGeomB g;
+};
+
+// WIDE: V0 = joints of the first half, tpc1 = tiles of a clip's second half (tiles_per_clip counts both halves)
+template <int TERMS, bool BF16OUT, bool WIDE>
 __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
     const uint4 *__restrict__ pfrag, const float *__restrict__ x, int xsc, int xsp, const float *__restrict__ W12,
     const uint4 *__restrict__ Wp, const float *__restrict__ shift, void *y, int C, int T, int V, int ROWS,
-    int tiles_per_clip, int ntiles, int abl, unsigned long long *dbg) {
+    int tiles_per_clip, int ntiles, int abl, unsigned long long *dbg, int V0, int tpc1) {
 #ifdef STGCN_ABLATION  // in-kernel cycle stamps (diagnostic builds only; dbg == NULL otherwise)
 #define V6_STAMP(var) unsigned long long var = 0; if (dbg) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); }
 #define V6_ACC(slot, a, b) if (dbg) { tsum[slot] += (b) - (a); }
@@ -131,7 +154,9 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
     char *buf0 = ring + RING6;
     char *buf1 = buf0 + buf_bytes;
     uint4 *Fs = reinterpret_cast<uint4 *>(buf0 + max(2 * buf_bytes, 4 * EPI6));
-    const uint4 *Pf = Fs + 4 * ROWS;
+    // WIDE, three-term arithmetic: the half's 24 fragments (24 KiB) sit in the second image buffer, which is idle from the
+    // end of a tile's main loop to the next tile's first period (the budget has no 24 KiB of its own)
+    const uint4 *Pf = (WIDE && TERMS == 3) ? reinterpret_cast<const uint4 *>(buf1) : Fs + 4 * ROWS;
     const unsigned lds0 = (unsigned)(size_t)(lptr6_t)smem6;
     const unsigned ring_lds = lds0 + (unsigned)(ring - smem6);
     const unsigned pf_lds = lds0 + (unsigned)(reinterpret_cast<const char *>(Pf) - smem6);
@@ -144,65 +169,142 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
         const int bw = d >> 1, img = d & 1;
         dma16v6(wsrc + ((size_t)(bw * npairs + qsrc) * 2 + img) * 64, ring_lds + slot * PAIR6 + ((2 * wave + bw) * 2 + img) * FRAG6);
     };
-    auto dma_pfrag = [&](int tile) {         // 12 KiB: the clip's attention fragments -> Pf
-        const int n = tile / tiles_per_clip;
-        const uint4 *src = pfrag + (size_t)n * 12 * 64 + lane;
+    // tile -> clip, joint half and geometry.  WIDE: a clip's tiles alternate between the halves (half-0 tile i, half-1 tile i,
+    // ...; the first half may own one more), so that the two column halves of a frame range are written close in time
+    auto tile_info = [&](int tile) {
+        TileInfo6 ti;
+        ti.n = tile / tiles_per_clip;
+        const int r = tile - ti.n * tiles_per_clip;
+        int idx;
+        if (r < 2 * tpc1) { ti.half = r & 1; idx = r >> 1; }
+        else { ti.half = 0; idx = r - tpc1; }
+        ti.Vh = ti.half ? V - V0 : V0;
+        ti.j0 = ti.half ? V0 : 0;
+        ti.g = tile_geom_b(idx, ti.Vh, KT6, 1, T, NP6);
+        return ti;
+    };
+    auto dma_pfrag = [&](int tile) {         // 12 KiB: the clip's attention fragments -> Pf  (WIDE: the half's 24 KiB)
+        if constexpr (WIDE) {
+            const TileInfo6 ti = tile_info(tile);
+            const uint4 *src = pfrag + ((size_t)ti.n * 48 + ti.half * 24) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) dma16v6(src + (wave + 4 * i) * 64, pf_lds + (wave + 4 * i) * FRAG6);
+            for (int i = 0; i < 6; ++i) dma16v6(src + (wave + 4 * i) * 64, pf_lds + (wave + 4 * i) * FRAG6);
+        } else {
+            const int n = tile / tiles_per_clip;
+            const uint4 *src = pfrag + (size_t)n * 12 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dma16v6(src + (wave + 4 * i) * 64, pf_lds + (wave + 4 * i) * FRAG6);
+        }
     };
 
     // ---- features of a tile from x and the clip's attention fragments (see stem_bf16_v4.hip, FK form) -------------
-    struct XRegs { float xa[8]; float xp[3]; };
+    struct XRegs { float xa[WIDE ? 16 : 8]; float xp[3]; };
     auto load_x = [&](XRegs &xr, int tile, int u) {
         int ln = tid & 63;                   // opaque per call: keeps lane-only address terms from being hoisted and spilled
         asm volatile("" : "+v"(ln));
         const int mb = u >> 1, hh = u & 1;
-        const int n = tile / tiles_per_clip;
-        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT6, 1, T, NP6);
+        TileInfo6 ti;
+        if constexpr (WIDE) ti = tile_info(tile);
+        else {
+            ti.n = tile / tiles_per_clip;
+            ti.g = tile_geom_b(tile - ti.n * tiles_per_clip, V, KT6, 1, T, NP6);
+        }
+        const int n = ti.n;
+        const TileGeomB g = ti.g;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(x + (size_t)n * 3 * TV), 0, (unsigned)(3 * TV * 4), 0x00020000);
         const int tf = g.t_first - (KT6 - 1) / 2 + 4 * mb;
-        {
+        if constexpr (WIDE) {
+            // (every offset is computed unconditionally and made opaque before the select: with the product inside the
+            //  conditional hipcc turns each of the 19 selects into a branch around its load)
             const int k = ln & 3, t = tf + ((ln & 15) >> 2), v0 = 8 * (ln >> 4);
-            const bool okr = k < 3 && t >= 0 && t < T;
+            const bool okr = (k < 3) & (t >= 0) & (t < T);
+            unsigned base = (unsigned)((k * xsc + (t * V + v0) * xsp) * 4);
+            asm volatile("" : "+v"(base));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned off = (okr && v0 + j < V) ? (unsigned)((k * xsc + (t * V + v0 + j) * xsp) * 4) : 0x7ffffff0u;
+            for (int j = 0; j < 16; ++j) {     // joints 0-31 and 32-63: the two k-steps of the aggregation
+                const int dv = (j & 7) + 32 * (j >> 3);
+                const unsigned off = (okr & (v0 + dv < V)) ? base + (unsigned)(dv * xsp * 4) : 0x7ffffff0u;   // (&: no short-circuit branch)
                 xr.xa[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
             }
-        }
-        {
-            const int t = tf + (ln >> 4), w = 16 * hh + (ln & 15);
-            const bool ok = t >= 0 && t < T && w < V;
+            const int t2 = tf + (ln >> 4), w = 16 * hh + (ln & 15);        // w: column within the half
+            const bool ok = (t2 >= 0) & (t2 < T) & (w < ti.Vh);
+            unsigned base2 = (unsigned)(((t2 * V + ti.j0 + w) * xsp) * 4);
+            asm volatile("" : "+v"(base2));
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const unsigned off = ok ? (unsigned)((k * xsc + (t * V + w) * xsp) * 4) : 0x7ffffff0u;
-                xr.xp[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+            for (int k2 = 0; k2 < 3; ++k2) {
+                const unsigned off = ok ? base2 + (unsigned)(k2 * xsc * 4) : 0x7ffffff0u;
+                xr.xp[k2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+            }
+        } else {
+            {
+                const int k = ln & 3, t = tf + ((ln & 15) >> 2), v0 = 8 * (ln >> 4);
+                const bool okr = k < 3 && t >= 0 && t < T;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned off = (okr && v0 + j < V) ? (unsigned)((k * xsc + (t * V + v0 + j) * xsp) * 4) : 0x7ffffff0u;
+                    xr.xa[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+                }
+            }
+            {
+                const int t = tf + (ln >> 4), w = 16 * hh + (ln & 15);
+                const bool ok = t >= 0 && t < T && w < V;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned off = ok ? (unsigned)((k * xsc + (t * V + w) * xsp) * 4) : 0x7ffffff0u;
+                    xr.xp[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+                }
             }
         }
     };
-    auto feature_unit = [&](const TileGeomB &g, int u, const XRegs &xr) {
+    auto feature_unit = [&](const TileInfo6 &ti, int u, const XRegs &xr) {
+        const TileGeomB &g = ti.g;
         int ln = tid & 63;
         asm volatile("" : "+v"(ln));
         const int mb = u >> 1, hh = u & 1;
-        uint4 xh, xl;
-        split8(xr.xa, xh, xl);
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, xh), al = __builtin_bit_cast(bf16x8, xl);
         f32x4 d[3];
+        if constexpr (WIDE) {
+            float xk[2][8];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, Pf[((s * 2 + hh) * 2 + 0) * 64 + ln]);
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, Pf[((s * 2 + hh) * 2 + 1) * 64 + ln]);
-            d[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bl, d[s], 0, 0, 0);
-            d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d[s], 0, 0, 0);
-            d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d[s], 0, 0, 0);
-            d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d[s], 0, 0, 0);
+            for (int j = 0; j < 16; ++j) xk[j >> 3][j & 7] = xr.xa[j];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) d[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 xh, xl;
+                split8(xk[ks], xh, xl);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, xh), al = __builtin_bit_cast(bf16x8, xl);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int f = ((s * 2 + hh) * 2 + ks) * 2;
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, Pf[(f + 0) * 64 + ln]);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, Pf[(f + 1) * 64 + ln]);
+                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bl, d[s], 0, 0, 0);
+                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d[s], 0, 0, 0);
+                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d[s], 0, 0, 0);
+                    d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d[s], 0, 0, 0);
+                }
+            }
+        } else {
+            uint4 xh, xl;
+            split8(xr.xa, xh, xl);
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, xh), al = __builtin_bit_cast(bf16x8, xl);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, Pf[((s * 2 + hh) * 2 + 0) * 64 + ln]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, Pf[((s * 2 + hh) * 2 + 1) * 64 + ln]);
+                d[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bl, d[s], 0, 0, 0);
+                d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d[s], 0, 0, 0);
+                d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d[s], 0, 0, 0);
+                d[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d[s], 0, 0, 0);
+            }
         }
+        const int Vh = ti.Vh;                                 // joints of this tile's pixel space (= V unless WIDE)
         const int w = 16 * hh + (ln & 15);
-        const int p = (4 * mb + (ln >> 4)) * V + w;          // pixel row of the tile
+        const int p = (4 * mb + (ln >> 4)) * Vh + w;         // pixel row of the tile
         const int gi = g.origin + p;
-        const bool valid = p < g.span && gi >= 0 && gi < TV; // else: the temporal conv's zero padding
+        const bool valid = p < g.span && gi >= 0 && gi < T * Vh; // else: the temporal conv's zero padding
         const float one = valid ? 1.f : 0.f;
         const float fa[8] = {d[0][0] * one, d[0][1] * one, d[0][2] * one, d[1][0] * one,
                              d[1][1] * one, d[1][2] * one, d[2][0] * one, d[2][1] * one};
@@ -210,7 +312,7 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
         uint4 ha, la, hb, lb;
         split8(fa, ha, la);
         split8(fb, hb, lb);
-        if (w < V && p < ROWS) {
+        if (w < Vh && p < ROWS) {
             Fs[p] = ha;
             Fs[(size_t)ROWS + p] = hb;
             Fs[(size_t)2 * ROWS + p] = la;
@@ -219,20 +321,27 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
     };
     // units wave, wave+4, wave+8 arrive prefetched; any further ones (narrow frames only) are loaded here
     auto feature_phase = [&](int tile, const XRegs &x0, const XRegs &x1, const XRegs &x2) {
-        const int n = tile / tiles_per_clip;
-        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT6, 1, T, NP6);
+        TileInfo6 ti;
+        if constexpr (WIDE) ti = tile_info(tile);
+        else {
+            ti.n = tile / tiles_per_clip;
+            ti.Vh = V;
+            ti.j0 = ti.half = 0;
+            ti.g = tile_geom_b(tile - ti.n * tiles_per_clip, V, KT6, 1, T, NP6);
+        }
+        const TileGeomB &g = ti.g;
         const int need = min(ROWS, ((g.span + 15) >> 4) << 4);       // rows the producer will read
-        const int nun = (((need + V - 1) / V + 3) >> 2) * 2;         // M-blocks x 2 joint halves
-        const bool two = V > 16;
+        const int nun = (((need + ti.Vh - 1) / ti.Vh + 3) >> 2) * 2; // M-blocks x 2 joint halves
+        const bool two = ti.Vh > 16;
         for (int u = wave; u < nun; u += 4) {
             if (!two && (u & 1)) continue;
-            if (u == wave) feature_unit(g, u, x0);
-            else if (u == wave + 4) feature_unit(g, u, x1);
-            else if (u == wave + 8) feature_unit(g, u, x2);
+            if (u == wave) feature_unit(ti, u, x0);
+            else if (u == wave + 4) feature_unit(ti, u, x1);
+            else if (u == wave + 8) feature_unit(ti, u, x2);
             else {
                 XRegs xr;
                 load_x(xr, tile, u);
-                feature_unit(g, u, xr);
+                feature_unit(ti, u, xr);
             }
         }
     };
@@ -307,8 +416,17 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
     int gq = 0, slot0 = 0, slot2 = 2, q2 = 2 % npairs;
     const int sel = lane >> 5, chh = (lane >> 4) & 1;   // B fragment lane groups: step of the pair, channel half
     for (; tile < ntiles; tile += gridDim.x) {
-        const int n = tile / tiles_per_clip;
-        const TileGeomB g = tile_geom_b(tile - n * tiles_per_clip, V, KT6, 1, T, NP6);
+        TileInfo6 ti;
+        if constexpr (WIDE) ti = tile_info(tile);
+        else {
+            ti.n = tile / tiles_per_clip;
+            ti.Vh = V;
+            ti.j0 = ti.half = 0;
+            ti.g = tile_geom_b(tile - ti.n * tiles_per_clip, V, KT6, 1, T, NP6);
+        }
+        const int n = ti.n;
+        const TileGeomB g = ti.g;
+        const int Vh = ti.Vh;
         const int nblk = (g.span + 15) >> 4;
         const int next_tile = tile + gridDim.x;
 
@@ -328,9 +446,9 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
         unsigned boff[KT6];
         {
             const int q = g.q0 + wave * 64 + (lane & 15);
-            const int prow = q - g.t_first * V;
+            const int prow = q - g.t_first * Vh;
 #pragma unroll
-            for (int tap = 0; tap < KT6; ++tap) boff[tap] = (unsigned)lds_off(prow + tap * V, chh);
+            for (int tap = 0; tap < KT6; ++tap) boff[tap] = (unsigned)lds_off(prow + tap * Vh, chh);
         }
         f32x4 acc[8][4];
 #pragma unroll
@@ -361,7 +479,8 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
         });
         const int nper = nch / 2;
         for (int per = 0; per < nper; ++per) {
-            if (per + 1 == nper && next_tile < ntiles) dma_pfrag(next_tile);   // Pf is idle after the tile's feature phase
+            if constexpr (!WIDE)
+                if (per + 1 == nper && next_tile < ntiles) dma_pfrag(next_tile);   // Pf is idle after the tile's feature phase
             static_for6<0, 9>([&](auto pi_c) {
                 constexpr int pi = decltype(pi_c)::value;
                 constexpr int l0 = 2 * pi;
@@ -475,6 +594,10 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
         // ---- epilogue: each 16-channel x 64-pixel block through this wave's 4 KiB staging slice, 16 B per lane ----------
         // D[row = channel 4*(lane>>4) + r][col = pixel lane&15] per 16x16 block.  Store addresses = scalar base + one
         // per-lane term; the last tile of a clip keeps per-lane bounds checks.
+        // WIDE: the second image buffer is idle from here on (every wave is past the last pair's barrier): the next tile's
+        // attention fragments go there now, land during the stores and are waited for in front of the feature phase
+        if constexpr (WIDE)
+            if (next_tile < ntiles) dma_pfrag(next_tile);
         XRegs xn0, xn1, xn2;                  // next tile's x: in flight while this tile's results are stored
         load_x(xn0, min(next_tile, ntiles - 1), wave);
         load_x(xn1, min(next_tile, ntiles - 1), wave + 4);
@@ -483,7 +606,76 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
         float *stg = reinterpret_cast<float *>(buf0 + wave * EPI6);
         const int qw = g.q0 + wave * 64;
         const bool full = g.q0 + NP6 - 1 <= g.q_last;            // (scalar) every pixel of the tile lies inside the clip
-        if (abl & OPT_OUT_NTVC) {
+        if constexpr (WIDE) {
+            // half-space pixel q = t*Vh + v'  ->  pixel t*V + j0 + v' of the clip
+            auto clip_pixel = [&](int q) { const int t = q / Vh; return t * V + ti.j0 + (q - t * Vh); };
+            if (abl & OPT_OUT_NTVC) {
+                // (N,T,V,C): as the narrow form, with the four pixels a lane stores mapped one by one
+                unsigned pt[4];
+                bool pok[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int q = qw + it * 16 + (lane >> 2);
+                    pok[it] = q <= g.q_last;
+                    pt[it] = (unsigned)(clip_pixel(min(q, g.q_last)) * C + 4 * (lane & 3));
+                }
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) {
+                    const int ob = cg * 128 + mb * 16;
+                    const float4 sh4 = *reinterpret_cast<const float4 *>(shift + ob + 4 * (lane >> 4));
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        const int px = nb * 16 + (lane & 15);
+                        const float4 v = make_float4(fmaxf(acc[mb][nb][0] + sh4.x, 0.f), fmaxf(acc[mb][nb][1] + sh4.y, 0.f),
+                                                     fmaxf(acc[mb][nb][2] + sh4.z, 0.f), fmaxf(acc[mb][nb][3] + sh4.w, 0.f));
+                        *reinterpret_cast<float4 *>(stg + px * 16 + (((lane >> 4) ^ (px & 3)) << 2)) = v;
+                    }
+                    const size_t tbase = (size_t)n * TV * C + ob;            // scalar
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int idx = it * 64 + lane, px = idx >> 2, sl = idx & 3;
+                        const float4 v = *reinterpret_cast<const float4 *>(stg + px * 16 + ((sl ^ (px & 3)) << 2));
+                        if (pok[it]) {
+                            if constexpr (BF16OUT)
+                                *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + tbase + pt[it]) =
+                                    make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                            else
+                                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + tbase + pt[it]) = v;
+                        }
+                    }
+                }
+            } else {
+                // (N,C,T,V): a lane owns ONE pair of pixels of the wave's 64 (2*(lane&31), +1: V, V0 and Vh are even, so a
+                // pair never straddles a frame or the halves and sits 8-byte aligned in the clip) and walks the 16 channel
+                // rows of a block two at a time: eight 8-byte stores per block
+                const int qp = qw + 2 * (lane & 31);
+                const bool pok = qp <= g.q_last;
+                const unsigned lterm = (unsigned)((lane >> 5) * TV + clip_pixel(min(qp, g.q_last)));
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) {
+                    const int ob = cg * 128 + mb * 16;
+                    const float4 sh4 = *reinterpret_cast<const float4 *>(shift + ob + 4 * (lane >> 4));
+                    const float shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            stg[(4 * (lane >> 4) + r) * 64 + nb * 16 + (lane & 15)] = fmaxf(acc[mb][nb][r] + shv[r], 0.f);
+                    const size_t tbase = ((size_t)n * C + ob) * TV;           // scalar
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const float2 v = *reinterpret_cast<const float2 *>(stg + (it * 2 + (lane >> 5)) * 64 + 2 * (lane & 31));
+                        const size_t sbase = tbase + (size_t)(it * 2) * TV;    // scalar
+                        if (pok) {
+                            if constexpr (BF16OUT)
+                                *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned short *>(y) + sbase + lterm) = pack_bf16x2(v.x, v.y);
+                            else
+                                *reinterpret_cast<float2 *>(reinterpret_cast<float *>(y) + sbase + lterm) = v;
+                        }
+                    }
+                }
+            }
+        } else if (abl & OPT_OUT_NTVC) {
             // (N,T,V,C): staged pixel-major [64 px][16 ch]: a lane's four channels of a pixel are one 16-byte slot
             // (slot XOR-swizzled by the pixel: conflict-free b128 accesses); a store then writes 16 pixels x 64 B
             const unsigned lterm = (unsigned)((lane >> 2) * C + 4 * (lane & 3));
@@ -552,6 +744,10 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
         V6_STAMP(t_3)
         V6_ACC(3, t_2, t_3)
         if (next_tile < ntiles) {             // its fragments landed at the last stage barrier, its x during the stores;
+            if constexpr (WIDE) {             // (WIDE: fragments issued at the head of this epilogue — landed, then visible)
+                dma_wait6();
+                __syncthreads();
+            }
             feature_phase(next_tile, xn0, xn1, xn2);   // Fs lies behind the staging area: no barrier needed in front
             V6_STAMP(t_4)
             V6_ACC(5, t_3, t_4)
@@ -569,15 +765,23 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
 struct V6Plan {
     int rows = 0, tiles_per_clip = 0;
     size_t lds = 0;
+    int v0 = 0, tpc1 = 0;                     // WIDE: joints of the first half, tiles of a clip's second half
 };
 
+// rows of the image one (pixel space of Vh joints) tile needs; 0 when the producer cannot cover it
+inline int v6_rows(int T, int Vh, int K) {
+    int dt = ceil_div(NP6 - 1, Vh);
+    if (dt > T - 1) dt = T - 1;
+    const int span = (dt + K) * Vh;
+    if (ceil_div(ceil_div(span, 16), 4) > 8) return 0;       // producer: 3 + 3 + 2 blocks per wave and chunk
+    return (span + 15) / 16 * 16;
+}
+
+#ifndef STGCN_V6_WIDE
 inline bool plan_v6(int C, int T, int V, int K, int terms, V6Plan &pl) {
     if (K != KT6 || C % 128 != 0 || V > 32) return false;    // (C % 32 == 0: an even number of 16-channel chunks)
-    int dt = ceil_div(NP6 - 1, V);
-    if (dt > T - 1) dt = T - 1;
-    const int span = (dt + K) * V;
-    const int rows = (span + 15) / 16 * 16;
-    if (ceil_div(ceil_div(span, 16), 4) > 8) return false;   // producer: 3 + 3 + 2 blocks per wave and chunk
+    const int rows = v6_rows(T, V, K);
+    if (rows == 0) return false;
     const size_t buf = (size_t)rows * PXB * (terms == 3 ? 2 : 1);
     const size_t img = 2 * buf > (size_t)4 * EPI6 ? 2 * buf : (size_t)4 * EPI6;
     pl.lds = (size_t)C * W12P * 4 + RING6 + img + (size_t)rows * 64 + 12 * FRAG6;
@@ -586,6 +790,26 @@ inline bool plan_v6(int C, int T, int V, int K, int terms, V6Plan &pl) {
     pl.tiles_per_clip = ceil_div(T * V, NP6);
     return true;
 }
+#else
+inline bool plan_v6(int C, int T, int V, int K, int terms, V6Plan &pl) {
+    const int v0 = stem_wide_split(V);
+    if (K != KT6 || C % 128 != 0 || v0 == 0) return false;
+    const int r0 = v6_rows(T, v0, K), r1 = v6_rows(T, V - v0, K);
+    if (r0 == 0 || r1 == 0) return false;
+    const int rows = r0 > r1 ? r0 : r1;
+    const size_t buf = (size_t)rows * PXB * (terms == 3 ? 2 : 1);
+    const size_t img = 2 * buf > (size_t)4 * EPI6 ? 2 * buf : (size_t)4 * EPI6;
+    // the half's 24 fragments: inside the second image buffer with three terms (it must hold them), else behind Fs
+    if (terms == 3 && buf < (size_t)24 * FRAG6) return false;
+    pl.lds = (size_t)C * W12P * 4 + RING6 + img + (size_t)rows * 64 + (terms == 3 ? 0 : 24 * FRAG6);
+    if (pl.lds > (size_t)kLdsBytes) return false;
+    pl.rows = rows;
+    pl.v0 = v0;
+    pl.tpc1 = ceil_div(T * (V - v0), NP6);
+    pl.tiles_per_clip = ceil_div(T * v0, NP6) + pl.tpc1;
+    return pl.tiles_per_clip - pl.tpc1 >= pl.tpc1;           // (the interleaved tile order assumes it: V0 >= V - V0)
+}
+#endif
 
 template <int TERMS>
 int launch_v6(const uint4 *pf, const float *x, int xsc, int xsp, const float *W12, const uint4 *Wq, const float *shift, void *y,
@@ -593,15 +817,15 @@ int launch_v6(const uint4 *pf, const float *x, int xsc, int xsp, const float *W1
     const int ntiles = N * pl.tiles_per_clip;
     const dim3 grid(ntiles < num_cu ? ntiles : num_cu, C / 128, 1);
     if (bf16out) {
-        auto kern = stem_bf16_v6_kernel<TERMS, true>;
+        auto kern = stem_bf16_v6_kernel<TERMS, true, V6W>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT6), pl.lds, st, pf, x, xsc, xsp, W12, Wq, shift, y, C, T, V, pl.rows,
-                           pl.tiles_per_clip, ntiles, opt, debug_buffer());
+                           pl.tiles_per_clip, ntiles, opt, debug_buffer(), pl.v0, pl.tpc1);
     } else {
-        auto kern = stem_bf16_v6_kernel<TERMS, false>;
+        auto kern = stem_bf16_v6_kernel<TERMS, false, V6W>;
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));
         hipLaunchKernelGGL(kern, grid, dim3(NT6), pl.lds, st, pf, x, xsc, xsp, W12, Wq, shift, y, C, T, V, pl.rows,
-                           pl.tiles_per_clip, ntiles, opt, debug_buffer());
+                           pl.tiles_per_clip, ntiles, opt, debug_buffer(), pl.v0, pl.tpc1);
     }
     STGCN_LAUNCH_CHECK("stem_bf16_v6_kernel");
     return STGCN_OK;
@@ -609,13 +833,22 @@ int launch_v6(const uint4 *pf, const float *x, int xsc, int xsp, const float *W1
 
 }  // namespace
 
-bool stem_v6_supported(int C, int T, int V, int K, unsigned flags) {
+#ifndef STGCN_V6_WIDE
+#define V6_SUPPORTED stem_v6_supported
+#define V6_LAUNCH launch_stem_v6
+#else
+#define V6_SUPPORTED stem_v6w_supported
+#define V6_LAUNCH launch_stem_v6w
+#endif
+
+bool V6_SUPPORTED(int C, int T, int V, int K, unsigned flags) {
     const unsigned math = flags & STGCN_MATH_MASK;
     if (math != STGCN_MATH_BF16X3 && math != STGCN_MATH_BF16) return false;
     V6Plan pl;
     return T >= 1 && plan_v6(C, T, V, K, math == STGCN_MATH_BF16X3 ? 3 : 1, pl);
 }
 
+#ifndef STGCN_V6_WIDE
 // temporal weights (Cout,Cin,9) * scale -> KF6's pair order (same size as the 32x32x16 packing)
 int launch_tcn_pack_bf16_pairs(const float *W, const float *scale, void *Wq, int Cin, int Cout, hipStream_t st) {
     const size_t total = (size_t)Cin * Cout * KT6 * 2;
@@ -624,9 +857,10 @@ int launch_tcn_pack_bf16_pairs(const float *W, const float *scale, void *Wq, int
     STGCN_LAUNCH_CHECK("tcn_pack_bf16_pairs_kernel");
     return STGCN_OK;
 }
+#endif
 
-int launch_stem_v6(const float *x, bool x_ntvc, const void *pfrag, const void *prep_w12, const void *Wq, const float *shift,
-                   void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st) {
+int V6_LAUNCH(const float *x, bool x_ntvc, const void *pfrag, const void *prep_w12, const void *Wq, const float *shift,
+              void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st) {
     const unsigned math = flags & STGCN_MATH_MASK;
     const int terms = math == STGCN_MATH_BF16X3 ? 3 : 1;
     const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
@@ -634,7 +868,7 @@ int launch_stem_v6(const float *x, bool x_ntvc, const void *pfrag, const void *p
     V6Plan pl;
     if (!plan_v6(C, T, V, K, terms, pl))
         return fail(STGCN_ERR_UNSUPPORTED, "stem v6 kernel does not cover C=%d T=%d V=%d K=%d", C, T, V, K);
-    if ((size_t)3 * T * V * 4 >= ((size_t)1 << 31))
+    if ((size_t)3 * T * V * 4 >= ((size_t)1 << 31) || (size_t)T * V * C >= ((size_t)1 << 31))
         return fail(STGCN_ERR_UNSUPPORTED, "stem v6: clip of T=%d V=%d exceeds a buffer resource", T, V);
     int dev = 0, num_cu = 256;
     STGCN_HIP_CHECK(hipGetDevice(&dev));

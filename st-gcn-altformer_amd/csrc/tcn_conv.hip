@@ -619,14 +619,16 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
 // workspace of the fused stem: [ P : N*S*V*V floats, 256-B aligned ] then ONE of
 //   [ features : N*T*V x 64 B (16 features as bf16 hi + lo) ]   when the large-tile kernel serves the shape and reads
 //                                                                features (wide frames), or
-//   [ fragments: N x 12 KiB (attention matrices as bf16 hi/lo MFMA B fragments) ]  when it computes them itself, or
+//   [ fragments: N x 12 KiB (attention matrices as bf16 hi/lo MFMA B fragments; 48 KiB for wide frames) ]  when it computes
+//                                                                them itself, or
 //   [ x copy   : N*Cin*T*V floats, channel-major ]              with STGCN_IN_NTVC on the kernels that read x themselves
 static size_t stem_ws_p_bytes(int N, int V, int S) { return align_up((size_t)N * S * V * V * sizeof(float), 256); }
 
 size_t stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {
     size_t b = stem_ws_p_bytes(N, V, S);
     if (stem_v4_supported(Cin, C, T, V, K, S, flags))
-        b += stem_v4_features_in_kernel(C, T, V, K, flags) ? (size_t)N * 12 * 1024 : (size_t)N * T * V * 16 * sizeof(float);
+        b += stem_v4_features_in_kernel(C, T, V, K, flags) ? (size_t)N * (V > 32 ? 48 : 12) * 1024   // (wide frames: both joint halves)
+                                                           : (size_t)N * T * V * 16 * sizeof(float);
     else if (flags & STGCN_IN_NTVC) b += (size_t)N * Cin * T * V * sizeof(float);
     return b;
 }

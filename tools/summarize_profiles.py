@@ -32,7 +32,7 @@ def main():
         with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(head)
-            w.writerows(body[:12])
+            w.writerows(body[:int(os.environ.get("STGCN_PROFILE_ROWS", "12"))])
     counters = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         for f in newest(glob.glob(os.path.join(d, "*", "*counter_collection.csv"))):
@@ -40,7 +40,8 @@ def main():
                 name = r["Kernel_Name"]
                 if "stgcn" not in name:
                     continue
-                short = name.split("stgcn::(anonymous namespace)::")[-1].split("(")[0]
+                short = name.replace("void ", "").replace("stgcn::(anonymous namespace)::", "").replace("stgcn::", "")
+                short = short.split("(")[0]            # kernel<template args>, namespaces stripped
                 counters[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 counters[short]["_dur_ns_" + os.path.basename(d)].append(
                     int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -54,22 +55,30 @@ def main():
             m["hbm_read_bytes_per_launch_x2_corrected"] = m.get("FETCH_SIZE", 0.0) * 1024 * 2
             m["hbm_write_bytes_per_launch"] = m.get("WRITE_SIZE", 0.0) * 1024
             m["hbm_traffic_bytes_per_launch"] = m["hbm_read_bytes_per_launch_x2_corrected"] + m["hbm_write_bytes_per_launch"]
+        per_pass = [len(v) for c, v in cs.items() if c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES", "SQ_WAVE_CYCLES")]
+        m["launches_seen"] = max(per_pass) if per_pass else 0
         if "GRBM_GUI_ACTIVE" in m:
             cyc = m["GRBM_GUI_ACTIVE"] / 8.0
             m["clock_GHz"] = cyc / m["_dur_ns_pmc_sq1"]
             if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
                 m["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
         out[k] = m
+    prog = os.path.join(src, "program.txt")
+    if os.path.exists(prog):                         # tools/collect_counters.sh: any program, not only bench.py
+        out["_meta"] = {"program": open(prog).read().strip(), "collected_by": "tools/collect_counters.sh " + tag}
     log = os.path.join(src, "trace.log")
     if os.path.exists(log):
         for line in open(log):
             if line.startswith("{") and '"metric"' in line:
                 bench = json.loads(line)
+                if "config" not in bench:            # another program's result line (tools/train_step.py ...): keep it as is
+                    out.setdefault("_meta", {})["result_line"] = bench
+                    continue
                 json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
                 # what bench.py checks before quoting `roofline.traffic` from this file: same workload, same kernel sources
-                out["_meta"] = {"workload": bench["config"].get("workload_key"),
-                                "csrc_digest": bench["config"].get("csrc_digest"),
-                                "collected_by": "tools/collect_profiles.sh " + tag}
+                out["_meta"] = dict(out.get("_meta", {}), workload=bench["config"].get("workload_key"),
+                                    csrc_digest=bench["config"].get("csrc_digest"))
+                out["_meta"].setdefault("collected_by", "tools/collect_profiles.sh " + tag)
     json.dump(out, open(os.path.join(dst, f"{tag}_counters.json"), "w"), indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(dst)))
 

@@ -52,9 +52,10 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 HBM_PEAK = 8.0e12                       # B/s, MI355X spec (MI355X_MICROARCH.md); measured copy ~6.29e12
-MFMA_PEAK = {"f32": 157.3e12, "f32_valu": 157.3e12, "bf16": 2.5e15, "bf16x3": 2.5e15}   # dense FLOP/s
+MFMA_PEAK = {"f32": 157.3e12, "f32_valu": 157.3e12, "bf16": 2.5e15, "bf16x3": 2.5e15, "f16mx": 2.5e15}   # dense FLOP/s (16-bit rate)
 DTYPE_NAME = {"f32": "f32", "f32_valu": "f32", "bf16": "bf16",
-              "bf16x3": "bf16x3 (fp32 operands split hi+lo bf16, 3 MFMAs, fp32 accumulate)"}
+              "bf16x3": "bf16x3 (fp32 operands split hi+lo bf16, 3 MFMAs, fp32 accumulate)",
+              "f16mx": "f16mx (fp32 operands as fp16 + two e4m3 residual products on the scaled MFMA, fp32 accumulate)"}
 
 
 def build_stem(V, graph_name, math, seed=1234):
@@ -177,7 +178,7 @@ def main():
     ap.add_argument("--sub-batch", type=int, default=512, help="largest number of clips per stem pass in --global-clips mode")
     ap.add_argument("--frames", type=int, default=180)
     ap.add_argument("--graph", choices=["SHRE", "LMDHG"], default="SHRE")
-    ap.add_argument("--math", choices=["f32", "bf16x3", "bf16", "f32_valu"], default=os.environ.get("STGCN_MATH", "bf16x3"))
+    ap.add_argument("--math", choices=["f32", "bf16x3", "bf16", "f32_valu", "f16mx"], default=os.environ.get("STGCN_MATH", "bf16x3"))
     ap.add_argument("--no-fuse", action="store_true", help="two-stage path (intermediate through HBM)")
     ap.add_argument("--layout", choices=["nctv", "ntvc"], default="nctv",
                     help="nctv = the reference's call (contiguous (N,3,T,V) in, (N,C,T,V) out; the headline); ntvc = SURVEY "
@@ -296,8 +297,9 @@ def main():
     def kernel_name(math):
         from stgcn_amd import _capi
         if args.no_fuse:
-            return "tcn_bf16_v6_kernel" if math in ("bf16x3", "bf16") else "tcn_mfma_f32_kernel"
-        fl = F._flags({"f32": F.MATH_F32, "bf16x3": F.MATH_BF16X3, "bf16": F.MATH_BF16, "f32_valu": F.MATH_F32_VALU}[math], False)
+            return "tcn_bf16_v6_kernel" if math in ("bf16x3", "bf16", "f16mx") else "tcn_mfma_f32_kernel"
+        fl = F._flags({"f32": F.MATH_F32, "bf16x3": F.MATH_BF16X3, "bf16": F.MATH_BF16, "f32_valu": F.MATH_F32_VALU,
+                       "f16mx": F.MATH_F16MX}[math], False)
         return _capi.lib().stgcn_stem_kernel_name(3, 128, T, V, 9, 3, fl).decode() or "?"
 
     def workload_key(math):
@@ -310,7 +312,9 @@ def main():
         peak = MFMA_PEAK[math]
         kname = kernel_name(math)
         roof = {"bound": "mfma", "kernel": kname,
-                "issued_over_algorithmic_flops": 3 if math == "bf16x3" else 1,
+                # matrix-core cycles issued per algorithmic product, in units of one 16-bit MFMA: three bf16 terms, or fp16 +
+                # two scaled-e4m3 products at twice the 16-bit rate (+ the quarter-full tap-8 products: 10,752 / 4,608 cycles)
+                "issued_over_algorithmic_flops": 3 if math == "bf16x3" else (2.33 if math == "f16mx" else 1),
                 "achieved": round(achieved / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4),
                 "achieved_over_f32_matrix_peak": round(achieved / MFMA_PEAK["f32"], 3),

@@ -69,6 +69,13 @@ typedef enum {
  * model/unit_agcn.py:54,91).  Forward: normalises with running_mean / running_var, leaves both untouched, and saves them as
  * (mean, invstd).  Backward: mean and invstd are constants — dz = gamma*invstd*g, dgamma = sum g*xhat, dbeta = sum g. */
 #define STGCN_BN_FROZEN 0x200u
+/* stgcn_stem_* entry points, with STGCN_MATH_BF16X3: where the kernel covers the shape (V <= ~25 joints, C % 128 == 0, K = 9)
+ * the fused stem's temporal conv runs as fp16 x fp16 plus two block-scaled e4m3 residual products
+ * (v_mfma_scale_f32_16x16x128_f8f6f4) instead of three bf16 products: the same 1e-4 contract (measured 2-4e-5 of max|ref|,
+ * tools/math_error_2term.py) at two thirds of the matrix-core cycles.  Everything else about the call is unchanged; shapes
+ * outside the kernel run the three-bf16 kernels.  The flag must be the same in stgcn_stem_prep_bytes / _prepare /
+ * _ws_bytes / _attention / _tail (the prep blob carries a third weight packing, the workspace a per-clip bound). */
+#define STGCN_STEM_F16MX 0x400u
 
 int stgcn_version(void);
 const char *stgcn_last_error(void);

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * NW) void attention_folded_kernel(
     const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
     float *__restrict__ P, float *__restrict__ feat, uint4 *__restrict__ pfrag, int Cin, int T, int V, int inter_c,
     int S, int TC, int Rp, int feat_slice_off, int sq_behind, int xsc, int xsp, float *__restrict__ xcopy,
-    unsigned long long *dbg, int pf_v0) {
+    unsigned long long *dbg, int pf_v0, float *__restrict__ ybound) {
     // x element (channel k, pixel p) of a clip sits at k*xsc + p*xsp: (T*V, 1) for (N,Cin,T,V), (1, Cin) for (N,T,V,Cin).
     // xcopy (optional): channel-major copy of x for kernels downstream that read it in that layout.
 #ifdef STGCN_ABLATION  // in-kernel cycle stamps (diagnostic builds only)
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64 * NW) void attention_folded_kernel(
 
     const float *xn = x + (size_t)n * Cin * T * V;
     const int CV = Cin * V;
+    float xmax = 0.f;                      // max |x| of the clip (ybound)
     K1_STAMP(1)
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int tc = min(TC, T - t0);
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(64 * NW) void attention_folded_kernel(
                         const size_t idx = (size_t)min(k, Cin - 1) * xsc + ((size_t)t0 * V + min(e, tc * V - 1)) * xsp;
                         const float val = xn[idx];
                         xv[k][i] = ok ? val : 0.f;
+                        xmax = fmaxf(xmax, fabsf(xv[k][i]));
                     }
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
@@ -247,6 +249,29 @@ __global__ __launch_bounds__(64 * NW) void attention_folded_kernel(
         for (int e = tid; e < S * V * V; e += NTH) Pn[e] = Sm[e];
     }
     K1_STAMP(6)
+    // Optional: what bounds every value the fused kernel's producer can emit for this clip (stem_f16mx.hip scales its
+    // e4m3 operands by it): max|x| and, per subset, max|x| * max_w sum_v |P_s[v][w]|  (|u_s| = |sum_v x P_s[v][w]| <= that).
+    if (ybound != nullptr) {
+        float *xm_s = Ms + 64, *cs_s = Ms + 96;     // (the bilinear matrices at the head of Ms are no longer needed)
+        float m = xmax;
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+        if (lane == 0) xm_s[wave] = m;
+        if (tid < 4) cs_s[tid] = 0.f;
+        __syncthreads();
+        if (tid < S * V) {                 // one thread per (subset, column): its abs-sum, then the subset's maximum
+            const int s = tid / V, w = tid - s * V;
+            float a = 0.f;
+            for (int v = 0; v < V; ++v) a += fabsf(Sm[(s * V + v) * V + w]);
+            atomicMax(reinterpret_cast<unsigned *>(&cs_s[s]), __float_as_uint(a));     // (non-negative floats order like their bits)
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float xm = 0.f;
+            for (int i = 0; i < NW; ++i) xm = fmaxf(xm, xm_s[i]);
+            ybound[n * 4 + 0] = xm;
+            for (int s = 0; s < 3; ++s) ybound[n * 4 + 1 + s] = s < S ? xm * cs_s[s] : 0.f;
+        }
+    }
 
     // Optional feature pass for the fused stem (Cin = 3, S = 3 only): per pixel (t,w) the 12 graph-conv
     // features [u_0, u_1, u_2, x] with u_s[k] = sum_v x[k,t,v] P_s[v,w]  (model/unit_agcn.py:87-88), then a
@@ -652,7 +677,7 @@ bool attention_emits_features(int Cin, int V, int S) {
 
 int launch_attention(const float *x, const float *A_eff, const float *Wa, const float *ba,
                      const float *Wb, const float *bb, float *P, float *feat, int N, int Cin, int T, int V,
-                     int inter_c, int S, hipStream_t st, bool x_ntvc, float *xcopy, void *pfrag, int pf_v0) {
+                     int inter_c, int S, hipStream_t st, bool x_ntvc, float *xcopy, void *pfrag, int pf_v0, float *ybound) {
     const int xsc = x_ntvc ? 1 : T * V, xsp = x_ntvc ? Cin : 1;
     if (pfrag != nullptr && (Cin != 3 || S != 3 || (pf_v0 == 0 && V > 32) || feat != nullptr))
         return fail(STGCN_ERR_UNSUPPORTED, "attention: fragment output covers Cin=3, 3 subsets, V<=32 (got %d, %d, %d)", Cin, S, V);
@@ -664,6 +689,7 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
     if (feat != nullptr && !pl.ok)
         return fail(STGCN_ERR_UNSUPPORTED, "attention: V=%d too large for the feature pass", V);
     if (pfrag != nullptr && !pl.ok) return fail(STGCN_ERR_UNSUPPORTED, "attention: V=%d outside the folded kernel", V);
+    if (ybound != nullptr && (!pl.ok || S * V > 512)) return fail(STGCN_ERR_UNSUPPORTED, "attention: no bound output for V=%d", V);
     if (pl.ok) {
         const int TC = pl.TC, Rp = pl.Rp, slice_off = pl.slice_off;
         const size_t lds = pl.lds;
@@ -671,7 +697,7 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
     do {                                                                                               \
         STGCN_HIP_CHECK(allow_lds((attention_folded_kernel<MI, TSL>), lds));                           \
         hipLaunchKernelGGL((attention_folded_kernel<MI, TSL>), dim3(N), dim3(64 * TSL), lds, st, x, A_eff, \
-                           Wa, ba, Wb, bb, P, feat, (uint4 *)pfrag, Cin, T, V, inter_c, S, TC, Rp, slice_off, pl.sq_behind, xsc, xsp, xcopy, debug_buffer(), pf_v0); \
+                           Wa, ba, Wb, bb, P, feat, (uint4 *)pfrag, Cin, T, V, inter_c, S, TC, Rp, slice_off, pl.sq_behind, xsc, xsp, xcopy, debug_buffer(), pf_v0, ybound); \
     } while (0)
         if (pl.nw == 16) {
             if (pl.maxb <= 1) LAUNCH_FOLDED(1, 16);

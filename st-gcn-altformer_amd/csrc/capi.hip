@@ -234,7 +234,7 @@ const char *stgcn_stem_kernel_name(int Cin, int C, int T, int V, int K, int subs
     if (stem_v4_supported(Cin, C, T, V, K, subsets, flags)) {
         if (stem_v4_features_in_kernel(C, T, V, K, flags) &&
             (stem_v6_supported(C, T, V, K, flags) || stem_v6w_supported(C, T, V, K, flags)))
-            return "stem_bf16_v6_kernel";
+            return stem_f16mx_supported(C, T, V, K, flags) ? "stem_f16mx_kernel" : "stem_bf16_v6_kernel";
         return "stem_bf16_v4_kernel";
     }
     const unsigned math = flags & STGCN_MATH_MASK;
@@ -261,7 +261,8 @@ int stgcn_stem_attention(const float *x, const float *A_eff, const float *Wa, co
     return launch_attention(x, A_eff, Wa, ba, Wb, bb, (float *)ws, frags ? nullptr : fpart, N, Cin, T, V, inter_c, subsets,
                             (hipStream_t)stream, (flags & STGCN_IN_NTVC) != 0,
                             stem_ws_xcopy(ws, N, Cin, C, T, V, K, subsets, flags), frags ? fpart : nullptr,
-                            frags ? stem_wide_split(V) : 0);   // wide frames: fragments for the two joint halves
+                            frags ? stem_wide_split(V) : 0,    // wide frames: fragments for the two joint halves
+                            frags ? stem_ws_bounds(ws, N, Cin, C, T, V, K, subsets, flags) : nullptr);
 }
 
 int stgcn_stem_tail_prepared(const float *x, const void *ws, size_t ws_bytes, const void *prep, const float *t_shift,

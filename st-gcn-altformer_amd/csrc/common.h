@@ -102,7 +102,8 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
                      const float *Wb, const float *bb, float *P, float *feat, int N, int Cin, int T,
                      int V, int inter_c, int S, hipStream_t st, bool x_ntvc = false, float *xcopy = nullptr,
                      void *pfrag = nullptr,    // pfrag: (N,12,64) x 16 B attention B-fragments instead of features
-                     int pf_v0 = 0);           // > 0: wide frames, (N,48,64) x 16 B fragments for the joint split V0 | V - V0
+                     int pf_v0 = 0,            // > 0: wide frames, (N,48,64) x 16 B fragments for the joint split V0 | V - V0
+                     float *ybound = nullptr); // (N,4): max|x| and max|x| * largest column abs-sum of P_s per clip (KF7's scales)
 
 int launch_agcn_expand(const float *x, const float *P, const float *Wd, const float *bd,
                        const float *Wdown, const float *bdown, const float *bn_scale,
@@ -149,6 +150,12 @@ static inline int stem_wide_split(int V) {     // V0 (a multiple of 4: 16-byte a
     return (v0 <= 32 && V - v0 >= 1) ? v0 : 0;
 }
 bool stem_v6w_supported(int C, int T, int V, int K, unsigned flags);
+// ... and KF7 (stem_f16mx.hip, STGCN_STEM_F16MX): KF6 with fp16 x fp16 + two scaled-e4m3 residual products per k-step group
+bool stem_f16mx_supported(int C, int T, int V, int K, unsigned flags);
+size_t stem_f16mx_prep_bytes(int C, int K);
+int launch_stem_f16mx_prepare(const float *W12, const float *Wt, const float *t_scale, void *dst, int C, hipStream_t st);
+int launch_stem_f16mx(const float *x, bool x_ntvc, const void *pfrag, const void *bounds, const void *prep_w12, const void *mx_blob,
+                      const float *shift, void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st);
 int launch_stem_v6w(const float *x, bool x_ntvc, const void *pfrag, const void *prep_w12, const void *Wq, const float *shift,
                     void *out, int N, int C, int T, int V, int K, unsigned flags, hipStream_t st);
 int launch_tcn_pack_bf16_pairs(const float *W, const float *scale, void *Wq, int Cin, int Cout, hipStream_t st);
@@ -277,6 +284,7 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
                         int Cin, int C, int K, int S, unsigned flags, hipStream_t st);
 size_t stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int S, unsigned flags);
 float *stem_ws_features(void *ws, int N, int Cin, int C, int T, int V, int K, int S, unsigned flags);  // NULL if unused
+float *stem_ws_bounds(void *ws, int N, int Cin, int C, int T, int V, int K, int S, unsigned flags);    // NULL unless KF7 serves the shape
 float *stem_ws_xcopy(void *ws, int N, int Cin, int C, int T, int V, int K, int S, unsigned flags);     // NULL if unused
 int launch_stem(const float *x, const float *P, const float *feat, const void *prep, const float *t_shift,
                 void *out, int N, int Cin, int C, int T, int V, int S, int K, unsigned flags, hipStream_t st);

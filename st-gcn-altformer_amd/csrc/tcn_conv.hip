@@ -577,9 +577,16 @@ static bool stem_prep_has_pairs(int C, int K, unsigned flags) {
     return (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) && K == 9 && C % 128 == 0;
 }
 
+// STGCN_STEM_F16MX: a third packing (KF7, stem_f16mx.hip) behind the pair-order copy
+static bool stem_prep_has_f16mx(int C, int K, unsigned flags) {
+    return (flags & STGCN_STEM_F16MX) && (flags & STGCN_MATH_MASK) == STGCN_MATH_BF16X3 && stem_prep_has_pairs(C, K, flags);
+}
+static size_t stem_f16mx_offset(int C, int K, unsigned flags) { return stem_w12_bytes(C) + 2 * tcn_packed_single_bytes(C, C, K, flags); }
+
 size_t stem_prep_bytes(int Cin, int C, int K, int S, unsigned flags) {
     (void)Cin; (void)S;
-    return stem_w12_bytes(C) + tcn_packed_single_bytes(C, C, K, flags) * (stem_prep_has_pairs(C, K, flags) ? 2 : 1);
+    return stem_w12_bytes(C) + tcn_packed_single_bytes(C, C, K, flags) * (stem_prep_has_pairs(C, K, flags) ? 2 : 1) +
+           (stem_prep_has_f16mx(C, K, flags) ? align_up(stem_f16mx_prep_bytes(C, K), 256) : 0);
 }
 
 static bool stem_shape_ok(int Cin, int C, int V, int K, int S, int T) {
@@ -613,7 +620,9 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
     STGCN_LAUNCH_CHECK("stem_fold_kernel");
     int rc = launch_tcn_pack(Wt, t_scale, (char *)prep + stem_w12_bytes(C), C, C, K, flags, st);
     if (rc != STGCN_OK || !stem_prep_has_pairs(C, K, flags)) return rc;
-    return launch_tcn_pack_bf16_pairs(Wt, t_scale, (char *)prep + stem_w12_bytes(C) + tcn_packed_single_bytes(C, C, K, flags), C, C, st);
+    rc = launch_tcn_pack_bf16_pairs(Wt, t_scale, (char *)prep + stem_w12_bytes(C) + tcn_packed_single_bytes(C, C, K, flags), C, C, st);
+    if (rc != STGCN_OK || !stem_prep_has_f16mx(C, K, flags)) return rc;
+    return launch_stem_f16mx_prepare((const float *)prep, Wt, t_scale, (char *)prep + stem_f16mx_offset(C, K, flags), C, st);
 }
 
 // workspace of the fused stem: [ P : N*S*V*V floats, 256-B aligned ] then ONE of
@@ -624,13 +633,25 @@ int launch_stem_prepare(const float *Wd, const float *bd, const float *Wdown, co
 //   [ x copy   : N*Cin*T*V floats, channel-major ]              with STGCN_IN_NTVC on the kernels that read x themselves
 static size_t stem_ws_p_bytes(int N, int V, int S) { return align_up((size_t)N * S * V * V * sizeof(float), 256); }
 
+static size_t stem_ws_feat_bytes(int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {
+    if (!stem_v4_supported(Cin, C, T, V, K, S, flags)) return 0;
+    return stem_v4_features_in_kernel(C, T, V, K, flags) ? (size_t)N * (V > 32 ? 48 : 12) * 1024   // (wide frames: both joint halves)
+                                                         : (size_t)N * T * V * 16 * sizeof(float);
+}
+
 size_t stem_ws_bytes(int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {
     size_t b = stem_ws_p_bytes(N, V, S);
-    if (stem_v4_supported(Cin, C, T, V, K, S, flags))
-        b += stem_v4_features_in_kernel(C, T, V, K, flags) ? (size_t)N * (V > 32 ? 48 : 12) * 1024   // (wide frames: both joint halves)
-                                                           : (size_t)N * T * V * 16 * sizeof(float);
-    else if (flags & STGCN_IN_NTVC) b += (size_t)N * Cin * T * V * sizeof(float);
+    if (stem_v4_supported(Cin, C, T, V, K, S, flags)) {
+        b += stem_ws_feat_bytes(N, Cin, C, T, V, K, S, flags);
+        if (stem_f16mx_supported(C, T, V, K, flags)) b += align_up((size_t)N * 4 * sizeof(float), 256);   // per-clip bounds (KF7)
+    } else if (flags & STGCN_IN_NTVC) b += (size_t)N * Cin * T * V * sizeof(float);
     return b;
+}
+
+// (N,4) floats behind the fragments when KF7 serves the shape, else NULL
+float *stem_ws_bounds(void *ws, int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {
+    if (!stem_v4_supported(Cin, C, T, V, K, S, flags) || !stem_f16mx_supported(C, T, V, K, flags)) return nullptr;
+    return reinterpret_cast<float *>(static_cast<char *>(ws) + stem_ws_p_bytes(N, V, S) + stem_ws_feat_bytes(N, Cin, C, T, V, K, S, flags));
 }
 
 float *stem_ws_features(void *ws, int N, int Cin, int C, int T, int V, int K, int S, unsigned flags) {
@@ -648,9 +669,14 @@ int launch_stem(const float *x, const float *P, const float *feat, const void *p
     const unsigned math = flags & STGCN_MATH_MASK;
     const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
     if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "stem: N=%d > 65535 clips per call", N);
-    if (feat != nullptr && stem_v4_supported(Cin, C, T, V, K, S, flags))
+    if (feat != nullptr && stem_v4_supported(Cin, C, T, V, K, S, flags)) {
+        if (stem_f16mx_supported(C, T, V, K, flags) && stem_v4_features_in_kernel(C, T, V, K, flags) && !(ablate_mask() & 512))
+            return launch_stem_f16mx(x, (flags & STGCN_IN_NTVC) != 0, feat,
+                                     (const char *)feat + stem_ws_feat_bytes(N, Cin, C, T, V, K, S, flags), prep,
+                                     (const char *)prep + stem_f16mx_offset(C, K, flags), t_shift, out, N, C, T, V, K, flags, st);
         return launch_stem_v4(x, (flags & STGCN_IN_NTVC) != 0, feat, prep, (const char *)prep + stem_w12_bytes(C), t_shift,
                               out, N, C, T, V, K, flags, st);
+    }
     if (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) {
         if (Cin != 3 || S != 3)
             return fail(STGCN_ERR_UNSUPPORTED, "stem: fused kernel covers Cin=3, 3 subsets (got %d, %d)", Cin, S);

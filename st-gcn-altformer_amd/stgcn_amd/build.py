@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "include"))
 LIB = os.path.join(HERE, "libstgcn_hip.so")
-SOURCES = ["capi.hip", "agcn_attention.hip", "agcn_expand.hip", "tcn_conv.hip", "tcn_bf16.hip", "stem_bf16_v4.hip", "stem_bf16_v6.hip", "stem_bf16_v6w.hip", "tcn_bf16_v6.hip", "train_bn.hip", "tcn_backward.hip", "tcn_wgrad_v6.hip", "agcn_backward.hip", "agcn_train.hip", "gemm_f32.hip", "agcn_backward_generic.hip"]
+SOURCES = ["capi.hip", "agcn_attention.hip", "agcn_expand.hip", "tcn_conv.hip", "tcn_bf16.hip", "stem_bf16_v4.hip", "stem_bf16_v6.hip", "stem_bf16_v6w.hip", "stem_f16mx.hip", "tcn_bf16_v6.hip", "train_bn.hip", "tcn_backward.hip", "tcn_wgrad_v6.hip", "agcn_backward.hip", "agcn_train.hip", "gemm_f32.hip", "agcn_backward_generic.hip"]
 ARCH = "gfx950"
 
 

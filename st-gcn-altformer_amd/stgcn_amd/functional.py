@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _capi
-from ._capi import MATH_BF16, MATH_BF16X3, MATH_F32, MATH_F32_VALU, OUT_BF16  # noqa: F401 (re-export)
+from ._capi import MATH_BF16, MATH_BF16X3, MATH_F16MX, MATH_F32, MATH_F32_VALU, OUT_BF16  # noqa: F401 (re-export)
 
 BN_EPS = 1e-5
 
@@ -36,7 +36,8 @@ def _stream(device) -> c_void_p:
 
 
 def _flags(math: int, out_bf16: bool) -> int:
-    return (math & _capi.MATH_MASK) | (OUT_BF16 if out_bf16 else 0)
+    # (MATH_F16MX = MATH_BF16X3 | STEM_F16MX: the extra bit only means something to the stgcn_stem_* entry points)
+    return (math & (_capi.MATH_MASK | _capi.STEM_F16MX)) | (OUT_BF16 if out_bf16 else 0)
 
 
 def bn_fold(weight, bias, running_mean, running_var, conv_bias=None, eps: float = BN_EPS):

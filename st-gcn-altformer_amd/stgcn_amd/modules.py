@@ -20,9 +20,9 @@ import torch
 import torch.nn as nn
 
 from . import functional as F
-from ._capi import MATH_BF16, MATH_BF16X3, MATH_F32, MATH_F32_VALU
+from ._capi import MATH_BF16, MATH_BF16X3, MATH_F16MX, MATH_F32, MATH_F32_VALU
 
-_MATH_NAMES = {"f32": MATH_F32, "bf16x3": MATH_BF16X3, "bf16": MATH_BF16, "f32_valu": MATH_F32_VALU}
+_MATH_NAMES = {"f32": MATH_F32, "bf16x3": MATH_BF16X3, "bf16": MATH_BF16, "f32_valu": MATH_F32_VALU, "f16mx": MATH_F16MX}
 
 
 def _default_math() -> int:

@@ -20,7 +20,10 @@ def sub_state(g, prefix):
 # arithmetic modes of the temporal-conv contraction and their gates:
 #   f32 / f32_valu / bf16x3 : the fp32 contract of north_star — 1e-4 relative (both criteria below)
 #   bf16                    : operands rounded to bf16; documented looser bound 1e-2*max|ref| (max-norm only)
-MATH_GATES = {"f32": (1e-4, True), "f32_valu": (1e-4, True), "bf16x3": (1e-4, True), "bf16": (1e-2, False)}
+#   f16mx                   : fused stem only (STGCN_STEM_F16MX, opt-in): fp16 x fp16 + two scaled-e4m3 residual products —
+#                             inside north_star's 1e-4*max|ref| (measured 2e-5, tools/math_error_2term.py) but NOT inside the
+#                             mixed allclose criterion (its error on near-zero outputs is ~2e-5*max|ref| > atol): max-norm only
+MATH_GATES = {"f32": (1e-4, True), "f32_valu": (1e-4, True), "bf16x3": (1e-4, True), "bf16": (1e-2, False), "f16mx": (1e-4, False)}
 
 
 def parity_gate(out, ref, rel=1e-4, what="", strict=True):

@@ -1449,3 +1449,161 @@ def test_moment_form_backward_refuses_statistics_without_moments(dev):
     bad = bwd(P2, None, None, stats2, y2)              # the mis-paired call of the advisor's report
     for k in ("dWd", "dbd", "dWdown", "dbdown", "dgamma", "dbeta", "ddgamma", "ddbeta", "dPA", "dWa", "dWb"):
         assert torch.isnan(bad[k]).all(), f"{k}: a mis-paired moment-form backward must not return numbers"
+
+
+# ---------------------------------------------------------------------------------------
+# round 3: KF6 over the two joint halves of a wide frame (stem_bf16_v6w.hip; VERDICT r2 #2: configs[3], V = 46)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("math", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("N,T,V", [(3, 40, 46),      # LMDHG: halves 24 | 22
+                                   (2, 200, 46),     # configs[3]'s clip length: 19 + 18 tiles per clip, interleaved
+                                   (5, 13, 34),      # halves 20 | 14 (one column block in the second half)
+                                   (2, 30, 48),      # 24 | 24: the widest frame whose halves the producer covers (<= 26 joints each)
+                                   (2, 25, 40),      # 20 | 20
+                                   (260, 12, 46)])   # more tiles than workgroups: the persistent loop, both halves per workgroup
+def test_wide_frame_stem_on_the_one_wave_kernel(N, T, V, math, dev):
+    """Frames of 32 < V <= 64 joints run through KF6 as two joint halves (the temporal conv never mixes joints; the
+    aggregation still sums over all V joints).  Against the fp64 oracle, fused == two-stage within the gate, and the kernel
+    name the library reports is the one-wave kernel (so a silent fallback to the eight-wave tile would show)."""
+    from stgcn_amd import _capi, enable_stem_fusion, functional as F, set_math_mode
+    from oracle import stgcn_oracle as so
+    fl = F._flags({"bf16x3": F.MATH_BF16X3, "bf16": F.MATH_BF16}[math], False)
+    assert _capi.lib().stgcn_stem_kernel_name(3, 128, T, V, 9, 3, fl).decode() == "stem_bf16_v6_kernel"
+    gcn, tcn, gp, tp, gen = _random_stem(V, None, 900 + T + V, dev)
+    set_math_mode(tcn, math)
+    enable_stem_fusion(gcn, tcn)
+    x = torch.randn(N, 3, T, V, generator=gen)
+    with torch.no_grad():
+        z = tcn(gcn(x.to(dev)))
+    pick = sorted({0, N // 2, N - 1})
+    aux = {}
+    ref = so.stem_forward(x[pick].double(), gp.to(torch.float64), tp.to(torch.float64), aux=aux)
+    rel, strict = MATH_GATES[math]
+    parity_gate(gcn.last_attention[pick], aux["gcn"]["P"], 1e-4, "P")
+    parity_gate(z[pick], ref, rel, f"wide stem V={V} T={T} {math}", strict)
+    if N > 8:                                  # clip independence across the persistent loop: a clip alone == the clip in the batch
+        with torch.no_grad():
+            alone = tcn(gcn(x[N - 3:N - 2].to(dev)))
+        assert torch.equal(alone[0], z[N - 3])
+
+
+@pytest.mark.parametrize("T,V", [(20, 35), (4, 46), (30, 64), (30, 50), (12, 62)])
+def test_wide_frames_outside_the_split_fall_back(T, V, dev):
+    """Odd V (rows would lose their 8-byte alignment), clips too short for the fragments to fit the idle image buffer, and
+    halves the producer cannot cover (more than 26 joints) keep the eight-wave kernel or the two-stage path — and stay
+    inside the gate."""
+    from stgcn_amd import _capi, enable_stem_fusion, functional as F
+    from oracle import stgcn_oracle as so
+    fl = F._flags(F.MATH_BF16X3, False)
+    assert _capi.lib().stgcn_stem_kernel_name(3, 128, T, V, 9, 3, fl).decode() != "stem_bf16_v6_kernel"
+    gcn, tcn, gp, tp, gen = _random_stem(V, None, 950 + T + V, dev)
+    enable_stem_fusion(gcn, tcn)
+    x = torch.randn(2, 3, T, V, generator=gen)
+    with torch.no_grad():
+        z = tcn(gcn(x.to(dev)))
+    parity_gate(z, so.stem_forward(x.double(), gp.to(torch.float64), tp.to(torch.float64)), 1e-4, f"fallback V={V} T={T}")
+
+
+# ---------------------------------------------------------------------------------------
+# round 3: KF7 — fp16 x fp16 + two block-scaled e4m3 residual products (stem_f16mx.hip, math mode "f16mx")
+# ---------------------------------------------------------------------------------------
+def _f16mx_name(T, V, C=128):
+    from stgcn_amd import _capi, functional as F
+    return _capi.lib().stgcn_stem_kernel_name(3, C, T, V, 9, 3, F._flags(F.MATH_F16MX, False)).decode()
+
+
+@pytest.mark.parametrize("case", ["stem_shre_T180", "stem_shre_T500"])
+def test_f16mx_stem_vs_golden(case, dev):
+    """The reference's own stem outputs (fixtures generated from the imported reference) at the fp32 gate, on KF7."""
+    from stgcn_amd import enable_stem_fusion
+    g = load_golden(case)
+    gcn = build_gcn(g, 3, 128, dev)
+    tcn = build_tcn(g, 128, 128, 9, 1, True, dev, "f16mx")
+    enable_stem_fusion(gcn, tcn)
+    x = torch.from_numpy(g["skeleton"]).to(dev).permute(0, 3, 1, 2).contiguous()
+    assert _f16mx_name(x.shape[2], 22) == "stem_f16mx_kernel"
+    with torch.no_grad():
+        z = tcn(gcn(x)).cpu()
+    scale = float(g["z_eval_absmax"])
+    err = (gather_flat(z, g["z_eval_idx"]).double() - torch.from_numpy(g["z_eval_val"]).double()).abs().max().item()
+    assert err <= 1e-4 * scale, f"{case} f16mx: {err:.3e} vs {scale:.3e}"
+    assert float(z.double().sum()) == pytest.approx(float(g["z_eval_sum"]), rel=1e-4, abs=1e-3 * scale)
+
+
+@pytest.mark.parametrize("N,T,V", [(3, 37, 22), (1, 5, 22), (2, 64, 24), (1, 1, 22), (2, 23, 7), (8, 180, 22), (300, 20, 22), (2, 90, 16)])
+def test_f16mx_stem_vs_oracle(N, T, V, dev):
+    """Ragged shapes, one-frame clips, narrow frames, more tiles than workgroups — against the fp64 oracle at the max-norm
+    gate of north_star (1e-4 of max|ref|)."""
+    from stgcn_amd import enable_stem_fusion, set_math_mode
+    from oracle import stgcn_oracle as so
+    assert _f16mx_name(T, V) == "stem_f16mx_kernel"
+    gcn, tcn, gp, tp, gen = _random_stem(V, None, 1200 + T + V, dev)
+    set_math_mode(tcn, "f16mx")
+    enable_stem_fusion(gcn, tcn)
+    x = torch.randn(N, 3, T, V, generator=gen)
+    with torch.no_grad():
+        z = tcn(gcn(x.to(dev)))
+    pick = sorted({0, N // 2, N - 1})
+    ref = so.stem_forward(x[pick].double(), gp.to(torch.float64), tp.to(torch.float64))
+    parity_gate(z[pick], ref, 1e-4, f"f16mx N={N} T={T} V={V}", strict=False)    # (typically 2e-5; up to ~6e-5 on very short clips)
+    if N > 8:
+        with torch.no_grad():
+            alone = tcn(gcn(x[N - 3:N - 2].to(dev)))
+        assert torch.equal(alone[0], z[N - 3])                        # clip independence across the persistent loop
+
+
+@pytest.mark.parametrize("unit", [1e-3, 1.0, 250.0, 3e4])
+def test_f16mx_scales_follow_the_input_magnitude(unit, dev):
+    """The e4m3 operands are pre-scaled by a per-clip bound (max|x| from K1 x weight norms from stgcn_stem_prepare), so the
+    result is as accurate for skeletons in millimetres (|x| ~ 1e3-1e4) or in kilometres as for unit-scale ones: no
+    saturation path.  One batch mixes clips of very different magnitude (the bound is per clip)."""
+    from stgcn_amd import enable_stem_fusion, set_math_mode
+    from oracle import stgcn_oracle as so
+    gcn, tcn, gp, tp, gen = _random_stem(22, None, 1300, dev)
+    set_math_mode(tcn, "f16mx")
+    enable_stem_fusion(gcn, tcn)
+    x = torch.randn(4, 3, 60, 22, generator=gen) * unit
+    x[1] *= 1e-2
+    x[2] *= 30.0
+    with torch.no_grad():
+        z = tcn(gcn(x.to(dev)))
+    ref = so.stem_forward(x.double(), gp.to(torch.float64), tp.to(torch.float64))
+    for n in range(4):                                                # per clip: each clip against ITS OWN scale
+        parity_gate(z[n], ref[n], 1e-4, f"f16mx clip {n} at unit {unit:g}", strict=False)
+
+
+@pytest.mark.parametrize("out_bf16", [False, True])
+def test_f16mx_layout_fusion_is_bit_exact(out_bf16, dev):
+    from stgcn_amd import enable_stem_fusion, set_math_mode, set_output_layout
+    gcn, tcn, gp, tp, gen = _random_stem(22, None, 1400, dev)
+    set_math_mode(tcn, "f16mx")
+    tcn.out_bf16 = out_bf16
+    enable_stem_fusion(gcn, tcn)
+    batch = torch.randn(21, 50, 22, 3, generator=gen).to(dev)
+    x_view = batch.permute(0, 3, 1, 2)
+    with torch.no_grad():
+        base = tcn(gcn(x_view.contiguous()))
+        assert torch.equal(tcn(gcn(x_view)), base)
+        set_output_layout(tcn, "channels_last")
+        z_cl = tcn(gcn(x_view))
+    assert z_cl.is_contiguous(memory_format=torch.channels_last) and torch.equal(z_cl, base)
+
+
+def test_f16mx_fallbacks(dev):
+    """Shapes outside KF7 (256 channels: the eight-wave kernel; wide frames: KF6 over the joint halves) silently keep the
+    three-bf16 kernels at the same gate; the two-stage path ignores the flag."""
+    from stgcn_amd import enable_stem_fusion, set_math_mode
+    from oracle import stgcn_oracle as so
+    assert _f16mx_name(40, 22, 256) == "stem_bf16_v4_kernel"
+    assert _f16mx_name(40, 46) == "stem_bf16_v6_kernel"
+    for V, c in ((22, 256), (46, 128)):
+        gcn, tcn, gp, tp, gen = _random_stem(V, None, 1500 + V, dev, c=c)
+        set_math_mode(tcn, "f16mx")
+        x = torch.randn(2, 3, 40, V, generator=gen)
+        ref = so.stem_forward(x.double(), gp.to(torch.float64), tp.to(torch.float64))
+        with torch.no_grad():
+            two = tcn(gcn(x.to(dev)))
+            enable_stem_fusion(gcn, tcn)
+            fused = tcn(gcn(x.to(dev)))
+        parity_gate(two, ref, 1e-4, f"two-stage V={V} C={c}")      # (neither runs KF7: the strict criterion holds)
+        parity_gate(fused, ref, 1e-4, f"fused V={V} C={c}")

@@ -496,6 +496,7 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
                 // weight fragments: current / next 16-channel block.  Block 0 of THIS pair was read during the previous one
                 // (ah0n / al0n): pairs gq and gq+1 are both resident and published at a pair's start (their DMAs are issued
                 // early in a pair and waited for at its end), so no pair opens with an exposed LDS read.
+                V6_STAMP(t_p0)                // (diagnostic builds: time per kind of pair, slots 4-7 of the stamp buffer)
                 uint4 ah[2], al[2];
                 ah[0] = ah0n;
                 if constexpr (TERMS == 3) al[0] = al0n;
@@ -577,6 +578,7 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
                 });
                 b_cur = b_nxt;
                 V6_STAMP(t_s1)
+                V6_ACC((pi == 4 ? 6 : (pi == 0 ? 7 : (pi == 3 ? 5 : 4))), t_p0, t_s1)
                 dma_wait6();                  // pair gq+2's weights (issued ~1,500 cycles ago) have landed
                 __syncthreads();              // ... and are visible; produced image rows are visible; slot gq%3 is free
                 V6_STAMP(t_s2)
@@ -750,11 +752,9 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
             }
             feature_phase(next_tile, xn0, xn1, xn2);   // Fs lies behind the staging area: no barrier needed in front
             V6_STAMP(t_4)
-            V6_ACC(5, t_3, t_4)
             __syncthreads();                  // Fs complete, every wave's staging reads done (chunk 0 overwrites buf0)
         }
         V6_STAMP(t_5)
-        V6_ACC(4, t_3, t_5)
     }
 #ifdef STGCN_ABLATION
     if (dbg && lane == 0 && blockIdx.x < 8 && blockIdx.y == 0)

@@ -523,6 +523,7 @@ __global__ __launch_bounds__(NT6) void stem_f16mx_kernel(
                     return i32x8{(int)r0.x & a8t_live, (int)r0.y & a8t_live, (int)r0.z & a8t_live, (int)r0.w & a8t_live,
                                  (int)r1.x & a8t_live, (int)r1.y & a8t_live, (int)r1.z & a8t_live, (int)r1.w & a8t_live};
                 };
+                V6_STAMP(t_p0)
                 uint4 ah[2];
                 ah[0] = ah0n;
                 i32x8 a8[2];
@@ -634,6 +635,7 @@ __global__ __launch_bounds__(NT6) void stem_f16mx_kernel(
                 });
                 b_cur = b_nxt;
                 V6_STAMP(t_s1)
+                V6_ACC((pi == 4 ? 6 : (pi == 0 ? 7 : (pi == 3 ? 5 : 4))), t_p0, t_s1)
                 dma_wait6();                  // pair gq+2's weights (issued early in this pair) have landed
                 __syncthreads();              // ... and are visible; produced image rows are visible; slot gq%3 is free
                 V6_STAMP(t_s2)
@@ -807,11 +809,9 @@ __global__ __launch_bounds__(NT6) void stem_f16mx_kernel(
             }
             feature_phase(next_tile, xn0, xn1, xn2);   // Fs lies behind the staging area: no barrier needed in front
             V6_STAMP(t_4)
-            V6_ACC(5, t_3, t_4)
             __syncthreads();                  // Fs complete, every wave's staging reads done (chunk 0 overwrites buf0)
         }
         V6_STAMP(t_5)
-        V6_ACC(4, t_3, t_5)
     }
 #ifdef STGCN_ABLATION
     if (dbg && lane == 0 && blockIdx.x < 8 && blockIdx.y == 0)

@@ -45,6 +45,10 @@ def build(force: bool = False, verbose: bool = False, keep_temps: bool = False, 
     if ablation:
         extra = os.environ.get("STGCN_EXTRA_DEFS", "").split()      # e.g. -DV6_NOFILL: one-off diagnostic variants
         return _build(LIB.replace(".so", "_abl.so"), "build_abl", ["-DSTGCN_ABLATION"] + extra, verbose, keep_temps)
+    variant = os.environ.get("STGCN_VARIANT")                       # A/B builds: libstgcn_hip_<variant>.so with STGCN_EXTRA_DEFS,
+    if variant:                                                     # no diagnostic code (load it with STGCN_LIB)
+        return _build(LIB.replace(".so", f"_{variant}.so"), f"build_{variant}", os.environ.get("STGCN_EXTRA_DEFS", "").split(),
+                      verbose, keep_temps)
     if not force and not _stale():
         return LIB
     return _build(LIB, "build", [], verbose, keep_temps)

@@ -63,6 +63,23 @@ __device__ __forceinline__ float relu1(float x) {
 
 using namespace bf16k;
 
+// Result stores of the NARROW kernel's epilogue: NON-TEMPORAL (round 3).  The 0.5 GB of output per launch pass through the same
+// 4 MiB L2s that serve the weight ring (2.4 GB per launch, re-read by every tile); streamed as `nt` whole 128-byte lines displace
+// less of it: 0.9-1.7 % off the kernel in same-box A/Bs of two libraries (tools/ab_libs.sh; write-through `sc1` stores
+// instead: 11 % slower).  The WIDE form keeps plain stores: its 8-byte pair stores fill a line from two workgroups a tile
+// apart, and pushed out early as `nt` halves they measured 3 % slower.  -DV6_PLAIN_STORES builds the plain form for that A/B.
+template <bool NT>
+__device__ __forceinline__ void st_out4(float *p, const float4 &v) {
+#ifndef V6_PLAIN_STORES
+    if constexpr (NT) {
+        using f32x4v = __attribute__((ext_vector_type(4))) float;
+        __builtin_nontemporal_store(f32x4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4v *>(p));
+        return;
+    }
+#endif
+    *reinterpret_cast<float4 *>(p) = v;
+}
+
 constexpr int NP6 = 256;   // output pixels per tile
 constexpr int NT6 = 256;   // threads per workgroup: one wave per SIMD
 constexpr int KT6 = 9;     // temporal taps
@@ -642,7 +659,7 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
                                 *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + tbase + pt[it]) =
                                     make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
                             else
-                                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + tbase + pt[it]) = v;
+                                st_out4<false>(reinterpret_cast<float *>(y) + tbase + pt[it], v);
                         }
                     }
                 }
@@ -703,7 +720,7 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
                             *reinterpret_cast<uint2 *>(yb + lterm) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
                         } else {
                             float *yb = reinterpret_cast<float *>(y) + tbase + (size_t)(it * 16) * C;
-                            *reinterpret_cast<float4 *>(yb + lterm) = v;
+                            st_out4<true>(yb + lterm, v);
                         }
                     }
                 }
@@ -733,7 +750,7 @@ __global__ __launch_bounds__(NT6) void stem_bf16_v6_kernel(
                             *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + sbase + lterm) =
                                 make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
                         else
-                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + sbase + lterm) = v;
+                            st_out4<true>(reinterpret_cast<float *>(y) + sbase + lterm, v);
                     } else {                                     // last tile of a clip / unaligned rows: element by element
                         const float e4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll

@@ -356,7 +356,12 @@ __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restric
                             *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + sbase + lterm) =
                                 make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
                         else
-                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(y) + sbase + lterm) = v;
+                            {   // non-temporal (round 3: whole lines streamed past the L2 that serves the weight ring: -0.7 % on the
+                                // training step, -1 % on the two-stage eval path in same-box A/Bs; see stem_bf16_v6.hip)
+                                using f32x4v = __attribute__((ext_vector_type(4))) float;
+                                __builtin_nontemporal_store(f32x4v{v.x, v.y, v.z, v.w},
+                                                            reinterpret_cast<f32x4v *>(reinterpret_cast<float *>(y) + sbase + lterm));
+                            }
                     } else {                                     // last tile of a clip / unaligned rows: element by element
                         const float e4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NT6) void stem_f16mx_kernel(
             e = max(-60, min(60, e));
             const int eY = __builtin_amdgcn_readfirstlane(14 - e);
             sY = __uint_as_float((unsigned)(eY + 127) << 23);
-            osc = __uint_as_float((unsigned)(127 - eY - (int)meta[5]) << 23);
+            osc = __uint_as_float((unsigned)max(1, min(254, 127 - eY - (int)meta[5])) << 23);   // (clamped: a valid power of two in any case)
         }
         constexpr float sH = 0.015625f, sL = 32.f;                          // 2^-6, 2^5
         constexpr int scYh = 127 + 6, scYl = 127 - 5;   // E8M0 bytes (byte 0 = opsel 0 of the scale operand) that undo them in the scaled MFMA

@@ -36,7 +36,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.dont_write_bytecode = True
 sys.path.insert(0, HERE)
 
-MODEL_SEED = 4242          # torch.manual_seed before constructing ST_GCN_AltFormer (stem first, then the heads)
+MODEL_SEED = 4246          # torch.manual_seed before constructing ST_GCN_AltFormer (stem first, then the heads); chosen (round 3) so that BOTH heads spread the 8 clips over several classes: ST 1,1,1,1,1,3,10,11 (smallest top-1/top-2 margin 9e-4), TS 8,8,8,8,8,0,3,3
 STEM_SEED = 4243           # generator of the stem randomisation and of the skeleton batch
 N_CLIPS, T, V, CLASSES = 8, 180, 22, 14
 
@@ -67,8 +67,9 @@ def install_timm_stub():
 
 def structured_clips(g):
     """Eight clips that differ in scale, offset and motion frequency.  (With i.i.d. randn clips the randomly
-    initialised heads answer the same class for every clip with a wide margin — an argmax test that cannot fail; these
-    clips spread the TS head over three classes with top-1/top-2 margins down to 1e-3 of a logit.)"""
+    initialised heads answer the same class for every clip with a wide margin — an argmax test that cannot fail; with these
+    clips and MODEL_SEED the ST head answers four classes with a smallest top-1/top-2 margin of 9e-4 of a logit, the TS head
+    three — ADVICE r2: with the round-2 seed the ST head said class 9 for all eight, which a degenerate head would pass too.)"""
     t = torch.arange(T, dtype=torch.float32).view(1, T, 1, 1) / T
     amp = torch.logspace(-1, 1, N_CLIPS).view(N_CLIPS, 1, 1, 1)
     freq = torch.randint(1, 12, (N_CLIPS, 1, V, 3), generator=g).float()

@@ -273,7 +273,7 @@ def test_full_size_properties(cfg, math, dev):
     parity_gate(z_fused[sel], ref, 1e-4, f"{cfg} full-size clips vs oracle")
 
 
-@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+@pytest.mark.parametrize("math", ["f32", "bf16x3", "f16mx"])
 def test_whole_model_stem_output_and_argmax_handoff(math, dev):
     """north_star's argmax clause, GPU half.  The fixture (tests/golden/make_golden_model.py) holds the reference
     ST_GCN_AltFormer's stem parameters, 8 skeleton clips, samples of the reference stem output z and the logits / argmax

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """north_star's "bit-exact for class-index argmax" clause, container half (needs /root/reference).
 
-    PYTHONDONTWRITEBYTECODE=1 python tools/argmax_check.py [gpurun_out/argmax] > profiles/r02_argmax_check.txt
+    PYTHONDONTWRITEBYTECODE=1 python tools/argmax_check.py [gpurun_out/argmax] > profiles/r03_argmax_check.txt
 
 The GPU test ``test_whole_model_stem_output_and_argmax_handoff`` wrote the HIP stem's output for the fixture's 8 clips
 (z_gpu_<math>.npy).  This script re-creates the reference ``ST_GCN_AltFormer`` from the fixture's seeds (imported from
@@ -38,7 +38,7 @@ def main():
         print(f"[{style}] reference model re-created from seed {mm.MODEL_SEED}: max |logits - fixture| = {dev0:.3e}")
         assert dev0 <= 1e-5 and np.array_equal(ref_logits.argmax(1), fix[f"argmax_{style}"])
         margin = fix[f"margin_{style}"]
-        for math in ("f32", "bf16x3"):
+        for math in ("f32", "bf16x3", "f16mx"):
             path = os.path.join(src, f"z_gpu_{math}.npy")
             if not os.path.exists(path):
                 print(f"[{style}] {math}: {path} missing (run the -m gpu suite first)")

@@ -255,12 +255,21 @@ struct GemmArgs {
     // and a small C (the per-clip weight-gradient slices, the joint Gram matrices) whose one tile per clip left most CUs idle.
     int ksplit = 1;
     long long c_ss = 0;
+    // optional two-level BATCH index (the chain's (clip, subset) products): b = bq*b_inner + br addresses A at
+    // bq*a_sb + br*a_sb2, B and C alike (b_inner = 0: single level)
+    int b_inner = 0;
+    long long a_sb2 = 0, b_sb2 = 0, c_sb2 = 0;
+    // optional two-level CONTRACTION index ((subset, joint) in dx += sum_s du_s P_s^T): k = kq*k_inner + kr addresses A at
+    // kq*a_sk + kr*a_sk2 and B at kq*b_sk + kr*b_sk2 (k_inner = 0: single level)
+    int k_inner = 0;
+    long long a_sk2 = 0, b_sk2 = 0;
 };
 int launch_gemm_f32(const GemmArgs &g, int batch, hipStream_t st);
-int launch_sum_parts(const float *part, float *out, int parts, size_t n, hipStream_t st);   // fixed order p = 0, 1, ...
+// out[rep*rep_stride + e] = sum_p part[p*n + e] in a fixed order, written `reps` times (one bias gradient shared by the subsets)
+int launch_sum_parts(const float *part, float *out, int parts, size_t n, hipStream_t st, int reps = 1, size_t rep_stride = 0);
 int launch_add_inplace(float *dst, const float *src, size_t n, hipStream_t st);
 int launch_row_sum(const float *in, float *out, int rows, int cols, hipStream_t st);
-int launch_softmax_bwd(const float *P, const float *A_eff, const float *dP, float *dS, int N, int V, int S, int s, float alpha,
+int launch_softmax_bwd(const float *P, const float *A_eff, const float *dP, float *dS, int N, int V, int S, float alpha,
                        hipStream_t st);
 
 // first patch embedding of the transformer heads on the stem output (gemm_f32.hip: one strided GEMM per clip)

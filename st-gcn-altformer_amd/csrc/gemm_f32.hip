@@ -8,9 +8,17 @@
 // matrices dP = x^T du, and the per-clip slices of the weight gradients (summed over clips afterwards, fixed order).
 // Arithmetic: v_mfma_f32_32x32x2_f32, i.e. exact fp32 fma chains — the backward's 1e-4 contract needs no hi/lo splitting.
 //
-// Workgroup = 64 x 64 tile of C, 256 threads = 4 waves (2 x 2 quadrants of 32 x 32), K walked in chunks of 16 through
-// LDS.  Tiles are loaded along whichever index has unit stride (coalesced when there is one); everything is bounds-checked,
-// so any M, N, K works (the joint matrices are 22 or 46 wide).
+// Workgroup = 256 threads = 4 waves, each on 32 x 32 blocks of C; K walked in chunks through LDS.  Three arrangements of the
+// four waves (template WM x WN x WK), picked per product by its shape:
+//   2 x 2 x 1   64 x 64 tile, K chunk 16 — the square-ish products (1x1 convolutions, their input / weight gradients)
+//   4 x 1 x 1   128 x 32 tile           — products whose N is one joint row (V = 22 / 25 / 46 <= 32: x.P, du.P^T, da / db):
+//                                         a 64-wide tile left half the waves on columns that do not exist
+//   1 x 1 x 4   32 x 32 tile, K chunk 64, the four waves on four quarters of every chunk, summed through LDS in the order
+//               0..3 — the joint Gram matrices dP = x^T du (V x V from K = C_in*T): on the 64 x 64 tile 8/9 of both operand
+//               loads were padding
+// Tiles are loaded along whichever index has unit stride (coalesced when there is one); everything is bounds-checked, so any
+// M, N, K works.  Optional two-level indices: the batch (clip, subset) and the contraction index (subset, joint), so that the
+// per-subset products of the chain run as ONE launch (agcn_backward_generic.hip).
 #include "common.h"
 
 namespace stgcn {
@@ -19,71 +27,92 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int GT = 64;    // tile edge (M and N)
-constexpr int GK = 16;    // K chunk
-constexpr int APAD = GK + 1;   // As[m][k] pitch: lanes run along m -> odd pitch, conflict-free fragment reads
-constexpr int BPAD = GT + 1;
-
+template <int WM, int WN, int WK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ float As[GT * APAD];
-    __shared__ float Bs[GK * BPAD];
+    static_assert(WM * WN * WK == 4, "four waves");
+    constexpr int TM = 32 * WM, TN = 32 * WN, KC = 16 * WK;
+    constexpr int APAD = KC + 1;      // As[m][k] pitch: lanes run along m -> odd pitch, conflict-free fragment reads
+    constexpr int BPAD = TN + 1;
+    constexpr int SMEM = TM * APAD + KC * BPAD;
+    static_assert(WK == 1 || SMEM >= WK * 1024, "the K-quarter sums reuse the operand tiles");
+    __shared__ float smem[SMEM];
+    float *As = smem, *Bs = smem + TM * APAD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WM, wn = (wave / WM) % WN, wk = wave / (WM * WN);
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
-    const int m0 = blockIdx.x * GT, n0 = blockIdx.y * GT, b = blockIdx.z / ks, part = blockIdx.z - b * ks;
-    const float *A = g.A + (size_t)b * g.a_sb;
-    const float *B = g.B + (size_t)b * g.b_sb;
-    float *C = g.C + (size_t)b * g.c_sb + (size_t)part * g.c_ss;
-    const int kc = ks > 1 ? ((g.K + ks - 1) / ks + GK - 1) / GK * GK : g.K;      // this part's share of K
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN, b = blockIdx.z / ks, part = blockIdx.z - b * ks;
+    const int bq = g.b_inner ? b / g.b_inner : b, br = g.b_inner ? b - bq * g.b_inner : 0;
+    const float *A = g.A + (size_t)bq * g.a_sb + (size_t)br * g.a_sb2;
+    const float *B = g.B + (size_t)bq * g.b_sb + (size_t)br * g.b_sb2;
+    float *C = g.C + (size_t)bq * g.c_sb + (size_t)br * g.c_sb2 + (size_t)part * g.c_ss;
+    const int kc = ks > 1 ? ((g.K + ks - 1) / ks + KC - 1) / KC * KC : g.K;      // this part's share of K
     const int k_lo = part * kc, k_hi = min(g.K, k_lo + kc);                       // (an empty part writes zeros)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool a_k_fast = g.a_sk == 1;     // consecutive threads along the unit-stride index of each operand
-    const bool b_n_fast = g.b_sn == 1 || g.b_sk != 1;
-    // the tile elements of this thread (GT*GK/256 = 4 of each operand), fetched one K chunk AHEAD into registers: the loads of
-    // chunk k0+GK are in flight while chunk k0 is multiplied (these products are small — the latency was all exposed)
-    constexpr int EPT = GT * GK / 256;
-    float ra[EPT], rb[EPT];
+    // consecutive threads along the unit-stride index of each operand
+    const bool a_k_fast = (g.k_inner ? g.a_sk2 : g.a_sk) == 1;
+    const bool b_n_fast = g.b_sn == 1 || (g.k_inner ? g.b_sk2 : g.b_sk) != 1;
+    // the tile elements of this thread, fetched one K chunk AHEAD into registers: the loads of chunk k0+KC are in flight
+    // while chunk k0 is multiplied (these products are small — the latency was all exposed)
+    constexpr int EA = TM * KC / 256, EB = KC * TN / 256;
+    float ra[EA], rb[EB];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
+        for (int i = 0; i < EA; ++i) {
             const int e = tid + i * 256;
-            const int m = a_k_fast ? e / GK : e % GT, k = a_k_fast ? e % GK : e / GT;
+            const int m = a_k_fast ? e / KC : e % TM, k = a_k_fast ? e % KC : e / TM;
             const int gm = m0 + m, gk = k0 + k;
             const int q = g.m_inner ? gm / g.m_inner : gm, r = g.m_inner ? gm - q * g.m_inner : 0;
-            ra[i] = (gm < g.M && gk < k_hi) ? A[(size_t)q * g.a_sm + (size_t)r * g.a_sm2 + (size_t)gk * g.a_sk] : 0.f;
+            const int kq = g.k_inner ? gk / g.k_inner : gk, kr = g.k_inner ? gk - kq * g.k_inner : 0;
+            ra[i] = (gm < g.M && gk < k_hi)
+                        ? A[(size_t)q * g.a_sm + (size_t)r * g.a_sm2 + (size_t)kq * g.a_sk + (size_t)kr * g.a_sk2] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
+        for (int i = 0; i < EB; ++i) {
             const int e = tid + i * 256;
-            const int k = b_n_fast ? e / GT : e % GK, n = b_n_fast ? e % GT : e / GK;
+            const int k = b_n_fast ? e / TN : e % KC, n = b_n_fast ? e % TN : e / KC;
             const int gk = k0 + k, gn = n0 + n;
-            rb[i] = (gk < k_hi && gn < g.N) ? B[(size_t)gk * g.b_sk + (size_t)gn * g.b_sn] : 0.f;
+            const int kq = g.k_inner ? gk / g.k_inner : gk, kr = g.k_inner ? gk - kq * g.k_inner : 0;
+            rb[i] = (gk < k_hi && gn < g.N) ? B[(size_t)kq * g.b_sk + (size_t)kr * g.b_sk2 + (size_t)gn * g.b_sn] : 0.f;
         }
     };
     if (k_lo < k_hi) fetch(k_lo);
-    for (int k0 = k_lo; k0 < k_hi; k0 += GK) {
+    for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
+        for (int i = 0; i < EA; ++i) {
             const int e = tid + i * 256;
-            const int m = a_k_fast ? e / GK : e % GT, k = a_k_fast ? e % GK : e / GT;
+            const int m = a_k_fast ? e / KC : e % TM, k = a_k_fast ? e % KC : e / TM;
             As[m * APAD + k] = ra[i];
         }
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
+        for (int i = 0; i < EB; ++i) {
             const int e = tid + i * 256;
-            const int k = b_n_fast ? e / GT : e % GK, n = b_n_fast ? e % GT : e / GK;
+            const int k = b_n_fast ? e / TN : e % KC, n = b_n_fast ? e % TN : e / KC;
             Bs[k * BPAD + n] = rb[i];
         }
         __syncthreads();
-        if (k0 + GK < k_hi) fetch(k0 + GK);
-        const float *ap = As + (wm * 32 + (lane & 31)) * APAD + (lane >> 5);
-        const float *bp = Bs + (lane >> 5) * BPAD + wn * 32 + (lane & 31);
+        if (k0 + KC < k_hi) fetch(k0 + KC);
+        const float *ap = As + (wm * 32 + (lane & 31)) * APAD + wk * 16 + (lane >> 5);
+        const float *bp = Bs + (wk * 16 + (lane >> 5)) * BPAD + wn * 32 + (lane & 31);
 #pragma unroll
-        for (int kk = 0; kk < GK / 2; ++kk)
+        for (int kk = 0; kk < 8; ++kk)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk], bp[2 * kk * BPAD], acc, 0, 0, 0);
+    }
+    if constexpr (WK > 1) {      // the four K quarters of the same 32 x 32 block: summed in the order 0, 1, 2, 3
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) smem[wk * 1024 + r * 64 + lane] = acc[r];
+        __syncthreads();
+        if (wk != 0) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float t = smem[r * 64 + lane];
+#pragma unroll
+            for (int j = 1; j < WK; ++j) t += smem[j * 1024 + r * 64 + lane];
+            acc[r] = t;
+        }
     }
     // D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
     const int gn = n0 + wn * 32 + (lane & 31);
@@ -102,25 +131,34 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-// out[e] = sum_{p < parts} part[p*n + e], deterministic: a workgroup owns 32 consecutive e; its 8 thread rows each sum one
-// eighth of the parts in the order p = lo, lo+1, ..., and the eight sub-sums are added in the order 0..7.  (One thread per
-// e walking all parts serially took 86 us for the 1024 parts of a split weight-gradient product.)
-__global__ __launch_bounds__(256) void sum_parts_kernel(const float *__restrict__ part, float *__restrict__ out, int parts,
-                                                       size_t n) {
-    __shared__ float sub[8][32];
+// out[rep*rep_stride + e] = sum_{p < parts} part[p*n + e], deterministic: a workgroup owns 32 consecutive e; its ROWS thread
+// rows each sum one ROWS-th of the parts in the order p = lo, lo+1, ... (loads issued four at a time), and the sub-sums are
+// added in the order 0..ROWS-1.  (One thread per e walking all parts serially took 86 us for the 1024 parts of a split
+// weight-gradient product; eight rows still 35 us for 960 parts of 4 K floats — 128 workgroups, 120 dependent loads each.)
+template <int ROWS>
+__global__ __launch_bounds__(32 * ROWS) void sum_parts_kernel(const float *__restrict__ part, float *__restrict__ out, int parts,
+                                                              size_t n, int reps, size_t rep_stride) {
+    __shared__ float sub[ROWS][32];
     const int le = threadIdx.x & 31, row = threadIdx.x >> 5;
     const size_t e = (size_t)blockIdx.x * 32 + le;
-    const int per = (parts + 7) / 8, lo = row * per, hi = min(parts, lo + per);
+    const int per = (parts + ROWS - 1) / ROWS, lo = row * per, hi = min(parts, lo + per);
     float a = 0.f;
-    if (e < n)
-        for (int p = lo; p < hi; ++p) a += part[(size_t)p * n + e];
+    if (e < n) {
+        int p = lo;
+        for (; p + 3 < hi; p += 4) {
+            const float v0 = part[(size_t)p * n + e], v1 = part[(size_t)(p + 1) * n + e], v2 = part[(size_t)(p + 2) * n + e],
+                        v3 = part[(size_t)(p + 3) * n + e];
+            a += v0; a += v1; a += v2; a += v3;
+        }
+        for (; p < hi; ++p) a += part[(size_t)p * n + e];
+    }
     sub[row][le] = a;
     __syncthreads();
     if (row == 0 && e < n) {
         float t = sub[0][le];
 #pragma unroll
-        for (int r = 1; r < 8; ++r) t += sub[r][le];
-        out[e] = t;
+        for (int r = 1; r < ROWS; ++r) t += sub[r][le];
+        for (int r = 0; r < reps; ++r) out[(size_t)r * rep_stride + e] = t;
     }
 }
 
@@ -147,14 +185,15 @@ __global__ __launch_bounds__(256) void row_sum_kernel(const float *__restrict__ 
     if (lane == 0) out[row] = a;
 }
 
-// Soft-max backward over v (dim -2) of one (clip, subset) matrix: Q = P - A_eff, dS = Q * (dP - colsum(Q * dP)) * alpha.
+// Soft-max backward over v (dim -2) of every (clip, subset) matrix: Q = P - A_eff, dS = Q * (dP - colsum(Q * dP)) * alpha.
+// P, dP, dS: [N][S][V][V]; one workgroup per matrix.
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float *__restrict__ P, const float *__restrict__ A_eff,
                                                          const float *__restrict__ dP, float *__restrict__ dS, int V,
-                                                         int S, int s, float alpha) {
+                                                         int S, float alpha) {
     extern __shared__ float dot[];   // [V]
-    const int n = blockIdx.x;
-    const float *Pn = P + ((size_t)n * S + s) * V * V, *Ae = A_eff + (size_t)s * V * V, *dPn = dP + (size_t)n * V * V;
-    float *dSn = dS + (size_t)n * V * V;
+    const int ns = blockIdx.x, s = ns % S;
+    const float *Pn = P + (size_t)ns * V * V, *Ae = A_eff + (size_t)s * V * V, *dPn = dP + (size_t)ns * V * V;
+    float *dSn = dS + (size_t)ns * V * V;
     for (int w = threadIdx.x; w < V; w += 256) {
         float d = 0.f;
         for (int v = 0; v < V; ++v) d = fmaf(Pn[v * V + w] - Ae[v * V + w], dPn[v * V + w], d);
@@ -172,10 +211,17 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float *__restric
 int launch_gemm_f32(const GemmArgs &g, int batch, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || batch <= 0) return fail(STGCN_ERR_ARG, "gemm: empty problem");
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
-    if ((long long)batch * ks > 65535 || ceil_div(g.N, GT) > 65535) return fail(STGCN_ERR_UNSUPPORTED, "gemm: grid too large");
     if (ks > 1 && (g.accumulate || g.bias || g.nbias || g.cbias))
         return fail(STGCN_ERR_ARG, "gemm: a split contraction writes plain partial sums (no bias, no accumulate)");
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(g.M, GT), ceil_div(g.N, GT), batch * ks), dim3(256), 0, st, g);
+    if (g.b_inner > 0 && batch % g.b_inner != 0) return fail(STGCN_ERR_ARG, "gemm: batch %d is not a multiple of its inner count %d", batch, g.b_inner);
+    // wave arrangement by shape (see the kernel's header)
+    const int form = (g.M <= 32 && g.N <= 32 && g.K >= 256) ? 2 : (g.N <= 32 ? 1 : 0);
+    const int TM = form == 0 ? 64 : (form == 1 ? 128 : 32), TN = form == 0 ? 64 : 32;
+    if ((long long)batch * ks > 65535 || ceil_div(g.N, TN) > 65535) return fail(STGCN_ERR_UNSUPPORTED, "gemm: grid too large");
+    const dim3 grid(ceil_div(g.M, TM), ceil_div(g.N, TN), batch * ks);
+    if (form == 0) hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1>), grid, dim3(256), 0, st, g);
+    else if (form == 1) hipLaunchKernelGGL((gemm_f32_kernel<4, 1, 1>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<1, 1, 4>), grid, dim3(256), 0, st, g);
     STGCN_LAUNCH_CHECK("gemm_f32_kernel");
     return STGCN_OK;
 }
@@ -205,8 +251,12 @@ int launch_patch_embed(const float *z, const float *W, const float *b, const flo
     return launch_gemm_f32(g, N, st);
 }
 
-int launch_sum_parts(const float *part, float *out, int parts, size_t n, hipStream_t st) {
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, out, parts, n);
+int launch_sum_parts(const float *part, float *out, int parts, size_t n, hipStream_t st, int reps, size_t rep_stride) {
+    const dim3 grid((unsigned)((n + 31) / 32));
+    if (parts >= 64)
+        hipLaunchKernelGGL((sum_parts_kernel<32>), grid, dim3(1024), 0, st, part, out, parts, n, reps, rep_stride);
+    else
+        hipLaunchKernelGGL((sum_parts_kernel<8>), grid, dim3(256), 0, st, part, out, parts, n, reps, rep_stride);
     STGCN_LAUNCH_CHECK("sum_parts_kernel");
     return STGCN_OK;
 }
@@ -223,9 +273,9 @@ int launch_row_sum(const float *in, float *out, int rows, int cols, hipStream_t 
     return STGCN_OK;
 }
 
-int launch_softmax_bwd(const float *P, const float *A_eff, const float *dP, float *dS, int N, int V, int S, int s, float alpha,
+int launch_softmax_bwd(const float *P, const float *A_eff, const float *dP, float *dS, int N, int V, int S, float alpha,
                        hipStream_t st) {
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(N), dim3(256), V * sizeof(float), st, P, A_eff, dP, dS, V, S, s, alpha);
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(N * S), dim3(256), V * sizeof(float), st, P, A_eff, dP, dS, V, S, alpha);
     STGCN_LAUNCH_CHECK("softmax_bwd_kernel");
     return STGCN_OK;
 }

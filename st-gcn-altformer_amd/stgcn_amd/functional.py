@@ -245,7 +245,7 @@ def agcn_forward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, bn, down_
     ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
     d = down_bn if down_bn is not None else (None, None, None, None)
     zm = torch.empty_like(y) if branches else None
-    zd = torch.empty_like(y) if branches else None
+    zd = torch.empty_like(y) if branches and down_bn is not None else None
     stats = torch.empty(4 * Cout + 128, device=dev, dtype=torch.float32) if save else None
     with torch.cuda.device(dev):
         _capi.call("stgcn_agcn_forward_train", _dev_ptr(x, "x", dev), _dev_ptr(A_eff, "A_eff", dev),

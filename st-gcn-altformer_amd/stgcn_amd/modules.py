@@ -164,17 +164,23 @@ class _AgcnTrainFn(torch.autograd.Function):
         d = mod.down[1] if has_down else None
         xd = x.detach()
         frozen = not mod._bn_training()              # .eval() under autograd: running statistics, constants of the backward
+        # The stem shape class (3 input channels, 3 subsets, batch statistics) derives its BatchNorm statistics from feature
+        # moments and writes neither pre-BatchNorm branch; its backward works from y — which the consumer keeps anyway — dy
+        # and those moments.  Every other call materialises the branches anyway: keep them for the backward (the deeper
+        # TCN_GCN_unit layers spent 0.13 - 0.42 ms per step rebuilding them with the expansion kernel).
+        moments = has_down and not frozen and x.shape[1] == 3 and mod.num_subset == 3
         y, P, zm, zd, stats = F.agcn_forward_train(
             xd, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], st["Wdown"], st["bdown"],
             (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var),
             (d.weight.detach(), d.bias.detach(), d.running_mean, d.running_var) if has_down else None,
-            bn.momentum, bn.eps, save=True, frozen=frozen)
-        # (zm, zd are None: the stem shape class derives its BatchNorm statistics from feature moments and writes
-        #  neither branch; its backward works from y — which the consumer keeps anyway — dy and those moments)
+            bn.momentum, bn.eps, save=True if moments else "branches", frozen=frozen)
         saved = [xd, st["A_eff"], st["Wa"], st["ba"], st["Wb"], st["bb"], st["Wd"], st["bd"], P, bn.weight.detach(),
                  bn.bias.detach(), stats, y]
         if has_down:
             saved += [st["Wdown"], st["bdown"], d.weight.detach(), d.bias.detach()]
+        ctx.branches = zm is not None
+        if ctx.branches:
+            saved += [zm] + ([zd] if has_down else [])
         ctx.save_for_backward(*saved)
         ctx.S = mod.num_subset
         ctx.has_down = has_down
@@ -187,8 +193,11 @@ class _AgcnTrainFn(torch.autograd.Function):
         t = ctx.saved_tensors
         x, A_eff, Wa, ba, Wb, bb, Wd, bd, P, bnw, bnb, stats, y = t[:13]
         Wdown, bdown, dbnw, dbnb = t[13:17] if ctx.has_down else (None, None, None, None)
+        rest = t[17:] if ctx.has_down else t[13:]
+        zm = rest[0] if ctx.branches else None
+        zd = rest[1] if ctx.branches and ctx.has_down else None
         need_dx = ctx.needs_input_grad[1]
-        g = F.agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, None, None, bnw, bnb, dbnw, dbnb, stats,
+        g = F.agcn_backward_train(x, A_eff, Wa, ba, Wb, bb, Wd, bd, Wdown, bdown, P, zm, zd, bnw, bnb, dbnw, dbnb, stats,
                                   dy.contiguous(), need_dx=need_dx, y=y, frozen=ctx.frozen)
         S = ctx.S
         out = [g["dPA"]]

@@ -478,6 +478,10 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, lq = lane >> 4;
     const int n = blockIdx.x;
+    // gridDim.y == S: one workgroup per (clip, subset) — batches with fewer clips than CUs (the deeper layers' 64-clip steps
+    // ran on 64 of 256 CUs); x is then staged once per subset (from L2 for the second and third).  gridDim.y == 1: all subsets.
+    const int only = gridDim.y > 1 ? (int)blockIdx.y : -1;
+    if (only > 0) xcopy = nullptr;
     float *Xs = smem;                                   // [Cin][PXC]
     float *Es = Xs + (size_t)Cin * PXC;                 // [2*inter_c][PXC]: a rows, then b rows (one subset at a time)
     const float *xn = x + (size_t)n * Cin * T * V;
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
         const int kpp = ((nk / 4 + KSP - 1) / KSP);     // k-steps per K part  (inter_c % 8 == 0: nk % 4 == 0)
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            if (s < S) {
+            if (s < S && (only < 0 || s == only)) {
                 __syncthreads();                        // Xs ready; the previous subset's Gram is done with Es
                 // ---- embeddings
                 for (int rb = wave % R8; rb < nrb; rb += R8) {
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
     float *Sm = parts + (size_t)S * KSP * VV;           // [S][V][V]
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        if (s < S) {
+        if (s < S && (only < 0 || s == only)) {
 #pragma unroll
             for (int i = 0; i < MAXB; ++i) {
                 const int unit = wave + 8 * i;
@@ -601,17 +605,19 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
     }
     __syncthreads();
     const float denom = (float)(inter_c * T);
-    for (int e = tid; e < S * VV; e += 512) {
+    const int e_lo = only < 0 ? 0 : only * VV, e_hi = only < 0 ? S * VV : e_lo + VV;
+    for (int e = e_lo + tid; e < e_hi; e += 512) {
         const int s = e / VV, vw = e - s * VV;
         float a = 0.f;
         for (int kq = 0; kq < KSP; ++kq) a += parts[((size_t)s * KSP + kq) * VV + vw];
         Sm[e] = a / denom;
     }
     __syncthreads();
-    softmax_columns(Sm, A_eff, S, V, 0, tid, 512);
+    if (only < 0) softmax_columns(Sm, A_eff, S, V, 0, tid, 512);
+    else softmax_columns(Sm + e_lo, A_eff, 1, V, only, tid, 512);
     __syncthreads();
     float *Pn = P + (size_t)n * S * VV;
-    for (int e = tid; e < S * VV; e += 512) Pn[e] = Sm[e];
+    for (int e = e_lo + tid; e < e_hi; e += 512) Pn[e] = Sm[e];
 }
 
 }  // namespace
@@ -732,7 +738,7 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
 #define LAUNCH_GMFMA(KSN, MB)                                                                                \
     do {                                                                                                     \
         STGCN_HIP_CHECK(allow_lds((attention_generic_mfma_kernel<KSN, MB>), lds));                           \
-        hipLaunchKernelGGL((attention_generic_mfma_kernel<KSN, MB>), dim3(N), dim3(512), lds, st, x, A_eff, Wa, ba, Wb, bb, P, \
+        hipLaunchKernelGGL((attention_generic_mfma_kernel<KSN, MB>), dim3(N, N * 2 <= 256 ? S : 1), dim3(512), lds, st, x, A_eff, Wa, ba, Wb, bb, P, \
                            Cin, T, V, inter_c, S, TC, PXC, xsc, xsp, xcopy);                                 \
     } while (0)
             if (per_wave <= 1) {

@@ -346,9 +346,15 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
         STGCN_HIP_CHECK(hipMemsetAsync(save_stats + 4 * Cout, 0, 128 * sizeof(float), st));
     hipLaunchKernelGGL(fill_ones_zeros_kernel, dim3(ceil_div(Cout, 256)), dim3(256), 0, st, ones, zeros, Cout);
     STGCN_LAUNCH_CHECK("fill_ones_zeros_kernel");
-    // main branch, pre-BN: sum_s conv_d_s(x P_s)   (unit scale on the main path, zero on the residual path, no ReLU)
-    rc = launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, ones, zeros, has_down ? zeros : nullptr,
-                            has_down ? zeros : nullptr, zm, N, Cin, Cout, T, V, subsets, 1 | 2, st);
+    // main branch, pre-BN: sum_s conv_d_s(x P_s)   (unit scale on the main path, zero on the residual path, no ReLU).
+    // Outside the stem class the residual rows are left out of the contraction altogether (no Wdown: "identity" with the
+    // residual term off, mode bit 1) and conv_down runs as one plain product below — the expansion kernel run a second time
+    // with the main scales at zero did the whole work of both branches again (2 x 208 us at 64 -> 128 channels, 64 clips).
+    const bool down_as_gemm = has_down && Cin != 3;
+    rc = down_as_gemm ? launch_agcn_expand(x, P_ws, Wd, bd, nullptr, nullptr, ones, zeros, nullptr, nullptr, zm, N, Cin, Cout, T, V,
+                                           subsets, 1 | 2, st)
+                      : launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, ones, zeros, has_down ? zeros : nullptr,
+                                           has_down ? zeros : nullptr, zm, N, Cin, Cout, T, V, subsets, 1 | 2, st);
     if (rc != STGCN_OK) return rc;
     if (frozen) {
         rc = launch_bn_frozen_finalize(bn_weight, bn_bias, bn_running_mean, bn_running_var, eps, s1, t1, Cout, st, sv_mm, sv_im);
@@ -360,8 +366,14 @@ int stgcn_agcn_forward_train(const float *x, const float *A_eff, const float *Wa
     }
     if (rc != STGCN_OK) return rc;
     if (has_down) {  // residual branch, pre-BN: conv_down(x)
-        rc = launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, zeros, zeros, ones, zeros, zd, N, Cin, Cout, T, V, subsets,
-                                1, st);
+        if (down_as_gemm) {     // zd[n] = Wdown x[n] + bdown
+            const long long Pl = (long long)plane;
+            GemmArgs g{Wdown, x, zd, bdown, Cout, (int)plane, Cin, Cin, 1, 0, Pl, 1, (long long)Cin * Pl, Pl, 1, (long long)Cout * Pl, 1.f, 0};
+            rc = launch_gemm_f32(g, N, st);
+        } else {
+            rc = launch_agcn_expand(x, P_ws, Wd, bd, Wdown, bdown, zeros, zeros, ones, zeros, zd, N, Cin, Cout, T, V, subsets,
+                                    1, st);
+        }
         if (rc != STGCN_OK) return rc;
         if (frozen) {
             rc = launch_bn_frozen_finalize(dbn_weight, dbn_bias, dbn_running_mean, dbn_running_var, eps, s2, t2, Cout, st, sv_md,

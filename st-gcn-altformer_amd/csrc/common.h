@@ -84,9 +84,16 @@ struct ChannelRows {
     }
 };
 
-// grid.x of those kernels: ~64 K elements per workgroup and channel, at most one workgroup per clip
-static inline int bn_chunks(int N, size_t plane) {
+// grid.x of those kernels: ~64 K elements per workgroup and channel, at most one workgroup per clip; tensors too small to
+// give a thousand workgroups that way (the deeper layers' 64-clip steps: 64 - 128 workgroups of 256 threads for the whole
+// chip, 0.5 TB/s) are cut finer, down to 8 K elements per workgroup and channel.
+static inline int bn_chunks(int N, size_t plane, int C = 0) {
     int chunks = (int)(((size_t)N * plane + 65535) / 65536);
+    if (C > 0 && chunks * C < 1024) {
+        const int fine = (int)(((size_t)N * plane + 8191) / 8192);
+        chunks = (1024 + C - 1) / C;
+        if (chunks > fine) chunks = fine;
+    }
     if (chunks > N) chunks = N;
     if (chunks > 64) chunks = 64;
     return chunks < 1 ? 1 : chunks;

@@ -53,45 +53,64 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     // consecutive threads along the unit-stride index of each operand
     const bool a_k_fast = (g.k_inner ? g.a_sk2 : g.a_sk) == 1;
     const bool b_n_fast = g.b_sn == 1 || (g.k_inner ? g.b_sk2 : g.b_sk) != 1;
-    // the tile elements of this thread, fetched one K chunk AHEAD into registers: the loads of chunk k0+KC are in flight
-    // while chunk k0 is multiplied (these products are small — the latency was all exposed)
+    // The tile elements of this thread: element i of A is (row m_i, local k kl_i) with either the k (k-fast: 256 % KC == 0)
+    // or the row (m-fast: 256 % TM == 0) shared by all i — so the row offsets (and their two-level split) are computed ONCE,
+    // and a chunk costs one multiply per operand plus adds (the offsets inside one batch entry fit 32 bits: checked by the
+    // launcher).  The first version recomputed four 64-bit products and two divisions per element and chunk: ~300 vector
+    // instructions per chunk against eight MFMAs.
     constexpr int EA = TM * KC / 256, EB = KC * TN / 256;
+    int a_ro[EA], b_co[EB];                    // row / column offset, or -1 outside the matrix
+    const int a_kl0 = a_k_fast ? tid % KC : tid / TM, a_dk = a_k_fast ? 0 : 256 / TM;   // local k of element i = a_kl0 + i*a_dk
+    const int b_kl0 = b_n_fast ? tid / TN : tid % KC, b_dk = b_n_fast ? 256 / TN : 0;
+#pragma unroll
+    for (int i = 0; i < EA; ++i) {
+        const int gm = m0 + (a_k_fast ? tid / KC + i * (256 / KC) : tid % TM);
+        const int q = g.m_inner ? gm / g.m_inner : gm, r = g.m_inner ? gm - q * g.m_inner : 0;
+        a_ro[i] = gm < g.M ? q * (int)g.a_sm + r * (int)g.a_sm2 : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < EB; ++i) {
+        const int gn = n0 + (b_n_fast ? tid % TN : tid / KC + i * (256 / KC));
+        b_co[i] = gn < g.N ? gn * (int)g.b_sn : -1;
+    }
+    const int a_sk = (int)g.a_sk, a_sk2 = (int)g.a_sk2, b_sk = (int)g.b_sk, b_sk2 = (int)g.b_sk2;
+    // fetched one K chunk AHEAD into registers: the loads of chunk k0+KC are in flight while chunk k0 is multiplied
+    // (these products are small — the latency was all exposed)
     float ra[EA], rb[EB];
     auto fetch = [&](int k0) {
+        if (g.k_inner == 0) {
+            const int ka = k0 + a_kl0, kb = k0 + b_kl0, oa = ka * a_sk, ob = kb * b_sk, da = a_dk * a_sk, db = b_dk * b_sk;
 #pragma unroll
-        for (int i = 0; i < EA; ++i) {
-            const int e = tid + i * 256;
-            const int m = a_k_fast ? e / KC : e % TM, k = a_k_fast ? e % KC : e / TM;
-            const int gm = m0 + m, gk = k0 + k;
-            const int q = g.m_inner ? gm / g.m_inner : gm, r = g.m_inner ? gm - q * g.m_inner : 0;
-            const int kq = g.k_inner ? gk / g.k_inner : gk, kr = g.k_inner ? gk - kq * g.k_inner : 0;
-            ra[i] = (gm < g.M && gk < k_hi)
-                        ? A[(size_t)q * g.a_sm + (size_t)r * g.a_sm2 + (size_t)kq * g.a_sk + (size_t)kr * g.a_sk2] : 0.f;
-        }
+            for (int i = 0; i < EA; ++i)
+                ra[i] = (a_ro[i] >= 0 && ka + i * a_dk < k_hi) ? A[a_ro[i] + oa + i * da] : 0.f;
 #pragma unroll
-        for (int i = 0; i < EB; ++i) {
-            const int e = tid + i * 256;
-            const int k = b_n_fast ? e / TN : e % KC, n = b_n_fast ? e % TN : e / KC;
-            const int gk = k0 + k, gn = n0 + n;
-            const int kq = g.k_inner ? gk / g.k_inner : gk, kr = g.k_inner ? gk - kq * g.k_inner : 0;
-            rb[i] = (gk < k_hi && gn < g.N) ? B[(size_t)kq * g.b_sk + (size_t)kr * g.b_sk2 + (size_t)gn * g.b_sn] : 0.f;
+            for (int i = 0; i < EB; ++i)
+                rb[i] = (b_co[i] >= 0 && kb + i * b_dk < k_hi) ? B[b_co[i] + ob + i * db] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < EA; ++i) {
+                const int gk = k0 + a_kl0 + i * a_dk, kq = gk / g.k_inner, kr = gk - kq * g.k_inner;
+                ra[i] = (a_ro[i] >= 0 && gk < k_hi) ? A[a_ro[i] + kq * a_sk + kr * a_sk2] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < EB; ++i) {
+                const int gk = k0 + b_kl0 + i * b_dk, kq = gk / g.k_inner, kr = gk - kq * g.k_inner;
+                rb[i] = (b_co[i] >= 0 && gk < k_hi) ? B[b_co[i] + kq * b_sk + kr * b_sk2] : 0.f;
+            }
         }
     };
+    // LDS slots of the same elements
+    const int a_ls = a_k_fast ? (tid / KC) * APAD + tid % KC : (tid % TM) * APAD + tid / TM;
+    const int a_ld = a_k_fast ? (256 / KC) * APAD : 256 / TM;
+    const int b_ls = b_n_fast ? (tid / TN) * BPAD + tid % TN : (tid % KC) * BPAD + tid / KC;
+    const int b_ld = b_n_fast ? (256 / TN) * BPAD : 256 / KC;
     if (k_lo < k_hi) fetch(k_lo);
     for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < EA; ++i) {
-            const int e = tid + i * 256;
-            const int m = a_k_fast ? e / KC : e % TM, k = a_k_fast ? e % KC : e / TM;
-            As[m * APAD + k] = ra[i];
-        }
+        for (int i = 0; i < EA; ++i) As[a_ls + i * a_ld] = ra[i];
 #pragma unroll
-        for (int i = 0; i < EB; ++i) {
-            const int e = tid + i * 256;
-            const int k = b_n_fast ? e / TN : e % KC, n = b_n_fast ? e % TN : e / KC;
-            Bs[k * BPAD + n] = rb[i];
-        }
+        for (int i = 0; i < EB; ++i) Bs[b_ls + i * b_ld] = rb[i];
         __syncthreads();
         if (k0 + KC < k_hi) fetch(k0 + KC);
         const float *ap = As + (wm * 32 + (lane & 31)) * APAD + wk * 16 + (lane >> 5);
@@ -116,16 +135,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
     // D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
     const int gn = n0 + wn * 32 + (lane & 31);
-    const float nb = (g.nbias && gn < g.N) ? g.nbias[gn] : 0.f;
+    if (gn >= g.N) return;
+    const float nb = g.nbias ? g.nbias[gn] : 0.f;
+    const int c_col = gn * (int)g.c_sn;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (gm < g.M && gn < g.N) {
+        if (gm < g.M) {
             const int cq = g.m_inner ? gm / g.m_inner : gm, cr = g.m_inner ? gm - cq * g.m_inner : 0;
             float v = g.alpha * acc[r] + nb;
             if (g.bias) v += g.bias[gm];
             if (g.cbias) v += g.cbias[(size_t)cq * g.cb_sq + (size_t)cr * g.cb_sr + (size_t)gn * g.cb_sn];
-            float *c = C + (size_t)cq * g.c_sm + (size_t)cr * g.c_sm2 + (size_t)gn * g.c_sn;
+            float *c = C + (cq * (int)g.c_sm + cr * (int)g.c_sm2 + c_col);
             *c = g.accumulate ? *c + v : v;
         }
     }
@@ -213,6 +234,18 @@ int launch_gemm_f32(const GemmArgs &g, int batch, hipStream_t st) {
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
     if (ks > 1 && (g.accumulate || g.bias || g.nbias || g.cbias))
         return fail(STGCN_ERR_ARG, "gemm: a split contraction writes plain partial sums (no bias, no accumulate)");
+    {   // offsets inside one batch entry are 32-bit in the kernel
+        auto span = [](long long n, long long inner, long long s1, long long s2) {
+            if (s1 < 0 || s2 < 0) return (long long)1 << 40;
+            return inner > 0 ? ((n - 1) / inner) * s1 + (inner - 1) * s2 : (n - 1) * s1;
+        };
+        const long long lim = ((long long)1 << 31) - 1;
+        const long long sa = span(g.M, g.m_inner, g.a_sm, g.a_sm2) + span(g.K, g.k_inner, g.a_sk, g.a_sk2);
+        const long long sb = span(g.K, g.k_inner, g.b_sk, g.b_sk2) + span(g.N, 0, g.b_sn, 0);
+        const long long sc = span(g.M, g.m_inner, g.c_sm, g.c_sm2) + span(g.N, 0, g.c_sn, 0);
+        if (sa > lim || sb > lim || sc > lim)
+            return fail(STGCN_ERR_UNSUPPORTED, "gemm: an operand of one batch entry spans more than 2^31 elements (or a negative stride)");
+    }
     if (g.b_inner > 0 && batch % g.b_inner != 0) return fail(STGCN_ERR_ARG, "gemm: batch %d is not a multiple of its inner count %d", batch, g.b_inner);
     // wave arrangement by shape (see the kernel's header)
     const int form = (g.M <= 32 && g.N <= 32 && g.K >= 256) ? 2 : (g.N <= 32 ? 1 : 0);

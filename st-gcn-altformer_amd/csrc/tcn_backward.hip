@@ -549,7 +549,7 @@ int launch_bn_relu_bwd_stats(const float *za, const float *sa, const float *ta, 
                              const float *dy, double *sums, int N, int C, size_t plane, hipStream_t st) {
     STGCN_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 3 * C, st));
     const BnSide a{za, sa, ta, ma, ia}, b{zb, sb, tb, mb, ib};
-    hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(bn_chunks(N, plane), C), dim3(256), 0, st, a, b, dy, sums, N,
+    hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(bn_chunks(N, plane, C), C), dim3(256), 0, st, a, b, dy, sums, N,
                        C, plane);
     STGCN_LAUNCH_CHECK("bn_relu_bwd_stats_kernel");
     return STGCN_OK;
@@ -570,7 +570,7 @@ int launch_bn_relu_bwd_apply(const float *za, const float *sa, const float *ta, 
                              int N, int C, size_t plane, hipStream_t st) {
     if (bsum) STGCN_HIP_CHECK(hipMemsetAsync(bsum, 0, sizeof(double) * 2 * C, st));
     const BnSide a{za, sa, ta, ma, ia}, b{zb, sb, tb, mb, ib};
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(bn_chunks(N, plane), C), dim3(256), 0, st, a, b, dy, coefa,
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(bn_chunks(N, plane, C), C), dim3(256), 0, st, a, b, dy, coefa,
                        coefb, dza, dzb, bsum, N, C, plane);
     STGCN_LAUNCH_CHECK("bn_relu_bwd_apply_kernel");
     return STGCN_OK;

@@ -141,7 +141,7 @@ int launch_bn_scale_shift(const float *weight, const float *bias, const float *m
 
 int launch_bn_batch_stats(const float *z, double *sums, int N, int C, size_t plane, hipStream_t st) {
     STGCN_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
-    hipLaunchKernelGGL(bn_batch_stats_kernel, dim3(bn_chunks(N, plane), C), dim3(256), 0, st, z, sums, N, C, plane);
+    hipLaunchKernelGGL(bn_batch_stats_kernel, dim3(bn_chunks(N, plane, C), C), dim3(256), 0, st, z, sums, N, C, plane);
     STGCN_LAUNCH_CHECK("bn_batch_stats_kernel");
     return STGCN_OK;
 }
@@ -167,7 +167,7 @@ int launch_bn_frozen_finalize(const float *weight, const float *bias, const floa
 int launch_bn_apply(const float *za, const float *sa, const float *ta, const float *zb, const float *sb,
                     const float *tb, float *y, size_t total, int C, size_t plane, hipStream_t st) {
     const int N = (int)(total / ((size_t)C * plane));
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_chunks(N, plane), C), dim3(256), 0, st, za, sa, ta, zb, sb, tb, y, N, C, plane);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_chunks(N, plane, C), C), dim3(256), 0, st, za, sa, ta, zb, sb, tb, y, N, C, plane);
     STGCN_LAUNCH_CHECK("bn_apply_kernel");
     return STGCN_OK;
 }

@@ -939,7 +939,8 @@ def test_eval_mode_backward_through_the_stem(dev):
     (32, 64, 2, 5, 7, "nctv"),        # one block, mostly padding
     (64, 64, 1, 1, 22, "nctv"),       # a single frame
     (64, 64, 2, 30, 64, "nctv"),      # widest graph the attention kernels take
-    (64, 64, 2, 23, 22, "ntvc")])     # channels-last input view
+    (64, 64, 2, 23, 22, "ntvc"),      # channels-last input view
+    (32, 64, 130, 6, 22, "nctv")])    # more than 128 clips: one workgroup per clip (up to 128: one per clip and subset)
 def test_generic_attention_on_matrix_cores_vs_oracle(cin, cout, N, T, V, layout, dev):
     """the adaptive adjacency of the deeper unit_agcn layers (model/unit_agcn.py:73-85 with C_in = 64..256:
     embeddings, Gram over (inter_c, T), column soft-max) runs on the fp32 matrix cores; P and the module output against the

@@ -500,12 +500,33 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int tc = min(TC, T - t0), px = tc * V, npb = (px + 15) / 16;
         __syncthreads();
-        for (int k = wave; k < Cin; k += 8) {            // a wave per channel row, lanes along the pixels: no index division
-            const float *xr = xn + (size_t)k * xsc + (size_t)t0 * V * xsp;
-            for (int p = lane; p < px; p += 64) {
-                const float xv = xr[(size_t)p * xsp];
-                Xs[k * PXC + p] = xv;
-                if (xcopy) xcopy[((size_t)n * Cin + k) * T * V + (size_t)t0 * V + p] = xv;
+        // a wave per channel row, lanes along the pixels: no index division.  Two rows x four 64-pixel pieces per trip, all
+        // eight loads issued before the first LDS store (one load per trip left the whole staging — 48 trips per chunk at 64
+        // channels — a chain of exposed memory round trips: most of this kernel's time at small batches)
+        for (int k = wave; k < Cin; k += 16) {
+            const bool two = k + 8 < Cin;
+            const float *xr0 = xn + (size_t)k * xsc + (size_t)t0 * V * xsp;
+            const float *xr1 = xr0 + (size_t)8 * xsc;
+            for (int p0 = lane; p0 < px; p0 += 256) {
+                float v0[4], v1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = p0 + 64 * q;
+                    v0[q] = p < px ? xr0[(size_t)p * xsp] : 0.f;
+                    v1[q] = (two && p < px) ? xr1[(size_t)p * xsp] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = p0 + 64 * q;
+                    if (p < px) {
+                        Xs[k * PXC + p] = v0[q];
+                        if (two) Xs[(k + 8) * PXC + p] = v1[q];
+                        if (xcopy) {
+                            xcopy[((size_t)n * Cin + k) * T * V + (size_t)t0 * V + p] = v0[q];
+                            if (two) xcopy[((size_t)n * Cin + k + 8) * T * V + (size_t)t0 * V + p] = v1[q];
+                        }
+                    }
+                }
             }
         }
         // contraction index of the Gram: idx = t * inter_c + c (inter_c is a power of two: shifts, no table)

@@ -561,14 +561,26 @@ int stgcn_tcn_forward_train(const float *x, const float *W, const float *conv_bi
     STGCN_LAUNCH_CHECK("fill_ones_zeros_kernel");
     int rc = launch_tcn_pack(W, ones, packed, Cin, Cout, K, flags, st);   // unit scale: the raw convolution
     if (rc != STGCN_OK) return rc;
-    rc = launch_tcn(x, packed, conv_bias ? conv_bias : zeros, z, N, Cin, Cout, T, V, K, stride,
-                    (flags & STGCN_MATH_MASK) | STGCN_RAW, st);
+    // the one-wave kernel sums the batch statistics in its epilogue (no separate pass over z)
+    const unsigned cflags = (flags & STGCN_MATH_MASK) | STGCN_RAW;
+#ifdef STGCN_NO_CONV_STATS    /* A/B builds: the separate statistics pass */
+    const bool stats_in_conv = false;
+#else
+    const bool stats_in_conv = !frozen && tcn_v6_supported(Cin, Cout, T, V, K, stride, cflags) && !(ablate_mask() & 8192);
+#endif
+    if (stats_in_conv) {
+        STGCN_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * Cout, st));
+        rc = launch_tcn_v6(x, packed + tcn_packed_single_bytes(Cin, Cout, K, cflags), conv_bias ? conv_bias : zeros, z, N, Cin, Cout,
+                           T, V, K, stride, cflags, st, sums);
+    } else {
+        rc = launch_tcn(x, packed, conv_bias ? conv_bias : zeros, z, N, Cin, Cout, T, V, K, stride, cflags, st);
+    }
     if (rc != STGCN_OK) return rc;
     if (frozen) {
         rc = launch_bn_frozen_finalize(bn_weight, bn_bias, bn_running_mean, bn_running_var, eps, s1, t1, Cout, st, save_mean,
                                        save_invstd);
     } else {
-        rc = launch_bn_batch_stats(z, sums, N, Cout, plane, st);
+        rc = stats_in_conv ? STGCN_OK : launch_bn_batch_stats(z, sums, N, Cout, plane, st);
         if (rc != STGCN_OK) return rc;
         rc = launch_bn_train_finalize(sums, (double)N * plane, bn_weight, bn_bias, bn_running_mean, bn_running_var, momentum,
                                       eps, s1, t1, Cout, st, save_mean, save_invstd);

@@ -176,7 +176,7 @@ bool tcn_v6_supported(int Cin, int Cout, int T, int V, int K, int stride, unsign
 bool tcn_v6_packs(int Cin, int Cout, int K, unsigned math);
 int launch_tcn_pack_pairs_padded(const float *W, const float *scale, void *Wq, int Cin, int Cout, hipStream_t st);
 int launch_tcn_v6(const float *x, const void *Wq, const float *shift, void *y, int N, int Cin, int Cout, int T, int V, int K,
-                  int stride, unsigned flags, hipStream_t st);
+                  int stride, unsigned flags, hipStream_t st, double *stats = nullptr);   // stats: see tcn_bf16_v6.hip
 int launch_tcn_v4(const float *x, const void *Wp, const float *shift, void *y, int N, int Cin, int Cout, int T, int V, int K,
                   int stride, unsigned flags, hipStream_t st);
 

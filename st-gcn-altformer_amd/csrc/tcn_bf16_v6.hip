@@ -74,10 +74,24 @@ __global__ void tcn_pack_pairs_padded_kernel(const float *__restrict__ W, const 
     Wq[e] = (unsigned short)(img ? l : h);
 }
 
-template <int TERMS, bool BF16OUT>
+// STATS (the training forward, model/net.py:40 in .train()): the epilogue also sums every output channel's values and
+// squares over the stored pixels — fp32 over the 64 pixels of a staged row, fp64 from there on (2 KiB of LDS per workgroup,
+// one pair of global fp64 atomics per workgroup and channel at the end) — into stats[c], stats[C + c]: the batch statistics
+// of BatchNorm without the separate pass over z (bn_batch_stats_kernel: 105 us of the stem's training step).
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));   // row_mirror
+    return v;
+}
+
+template <int TERMS, bool BF16OUT, bool STATS = false>
 __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restrict__ x, const uint4 *__restrict__ Wp,
                                                           const float *__restrict__ shift, void *y, int Cin, int C, int T, int V,
-                                                          int ROWS, int tiles_per_clip, int ntiles, float act_lo, int abl) {
+                                                          int ROWS, int tiles_per_clip, int ntiles, float act_lo, int abl,
+                                                          double *__restrict__ stats = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem6[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,6 +107,8 @@ __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restric
     char *buf1 = buf0 + buf_bytes;
     char *stage = buf1 + buf_bytes;
     const unsigned ring_lds = (unsigned)(size_t)(lptr6_t)smem6;
+    double *sstat = reinterpret_cast<double *>(stage + 4 * EPI6);     // STATS: [2][128] (sum, sum of squares)
+    if constexpr (STATS) sstat[tid] = 0.0;                            // (the main loop's barriers order this before the first add)
 
     const int cg = blockIdx.y;               // 128-channel group of the output
     // the four weight fragments this wave DMAs per pair: 16-channel blocks 2*wave, 2*wave+1, images hi and lo
@@ -347,10 +363,26 @@ __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restric
                         stg[(4 * (lane >> 4) + r) * 64 + nb * 16 + (lane & 15)] = fmaxf(acc[mb][nb][r] + shv[r], act_lo);
                 const size_t tbase = ((size_t)n * C + ob) * TV + qw;      // scalar
                 const bool al16 = ((tbase & 3) == 0) && (TV % 4 == 0);    // 16-byte (8-byte for bf16) aligned rows
+                [[maybe_unused]] float k1 = 0.f, k2 = 0.f;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const float4 v = *reinterpret_cast<const float4 *>(stg + (it * 4 + (lane >> 4)) * 64 + c4l);
                     const size_t sbase = tbase + (size_t)(it * 4) * TV;    // scalar
+                    if constexpr (STATS) {   // row (it*4 + lane>>4) of the block: 16 lanes x 4 pixels
+                        const float e4[4] = {v.x, v.y, v.z, v.w};
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = (full || qw + c4l + e <= g.q_last) ? e4[e] : 0.f;
+                            s1 += a;
+                            s2 = fmaf(a, a, s2);
+                        }
+                        // the row's 16 lanes: quad butterflies, then the mirrored half-row and row (DPP: no LDS round trip —
+                        // with ds_bpermute shuffles this cost more than the separate statistics pass it replaces)
+                        s1 = row16_sum(s1);
+                        s2 = row16_sum(s2);
+                        if ((lane & 15) == it) { k1 = s1; k2 = s2; }   // lane (lane & 15) = it keeps row it*4 + (lane >> 4)
+                    }
                     if (full && al16) {
                         if constexpr (BF16OUT)
                             *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(y) + sbase + lterm) =
@@ -369,6 +401,13 @@ __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restric
                             if (qw + c4l + e <= g.q_last) store_out<BF16OUT>(y, sbase + lterm + e, e4[e]);
                     }
                 }
+                if constexpr (STATS) {
+                    if ((lane & 15) < 4) {
+                        const int ch = mb * 16 + (lane & 15) * 4 + (lane >> 4);
+                        atomicAdd(&sstat[ch], (double)k1);
+                        atomicAdd(&sstat[128 + ch], (double)k2);
+                    }
+                }
             }
         }
         // the held element (next tile, chunk 1) becomes "current tile"
@@ -377,6 +416,11 @@ __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restric
         e_next = false;
     }
     vm_wait_keep<0>();                        // nothing of this workgroup stays in flight behind its end
+    if constexpr (STATS) {
+        __syncthreads();
+        const int ch = cg * 128 + (tid & 127);
+        if (ch < C) atomicAdd(&stats[(tid >> 7) * C + ch], sstat[tid]);
+    }
 }
 
 struct T6Plan {
@@ -425,8 +469,10 @@ int launch_tcn_pack_pairs_padded(const float *W, const float *scale, void *Wq, i
     return STGCN_OK;
 }
 
+// stats (optional, 2*Cout doubles ZEROED by the caller): per-channel sum and sum of squares of the stored output
+// (fp32, (N,C,T,V) layout only) — the training forward's batch statistics
 int launch_tcn_v6(const float *x, const void *Wq, const float *shift, void *y, int N, int Cin, int Cout, int T, int V, int K,
-                  int stride, unsigned flags, hipStream_t st) {
+                  int stride, unsigned flags, hipStream_t st, double *stats) {
     const unsigned math = flags & STGCN_MATH_MASK;
     const int terms = math == STGCN_MATH_BF16X3 ? 3 : 1;
     const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
@@ -441,12 +487,28 @@ int launch_tcn_v6(const float *x, const void *Wq, const float *shift, void *y, i
     STGCN_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntiles = N * pl.tiles_per_clip;
     const dim3 grid(ntiles < num_cu ? ntiles : num_cu, ceil_div(Cout, 128), 1);
+    if (stats != nullptr) {
+        if (bf16out || opt) return fail(STGCN_ERR_UNSUPPORTED, "tcn v6 kernel: channel statistics go with the fp32 (N,C,T,V) output");
+        const size_t lds = pl.lds + 2 * 128 * sizeof(double);
+        if (lds > (size_t)kLdsBytes) return fail(STGCN_ERR_UNSUPPORTED, "tcn v6 kernel: no LDS left for the channel statistics");
+#define LAUNCH_T6S(TERMS)                                                                                         \
+    do {                                                                                                          \
+        auto kern = tcn_bf16_v6_kernel<TERMS, false, true>;                                                       \
+        STGCN_HIP_CHECK(allow_lds(kern, lds));                                                                    \
+        hipLaunchKernelGGL(kern, grid, dim3(NT6), lds, st, x, (const uint4 *)Wq, shift, y, Cin, Cout, T, V, pl.rows, \
+                           pl.tiles_per_clip, ntiles, act_lo, opt, stats);                                        \
+    } while (0)
+        if (terms == 3) LAUNCH_T6S(3); else LAUNCH_T6S(1);
+#undef LAUNCH_T6S
+        STGCN_LAUNCH_CHECK("tcn_bf16_v6_kernel");
+        return STGCN_OK;
+    }
 #define LAUNCH_T6(TERMS, B)                                                                                       \
     do {                                                                                                          \
         auto kern = tcn_bf16_v6_kernel<TERMS, B>;                                                                 \
         STGCN_HIP_CHECK(allow_lds(kern, pl.lds));                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(NT6), pl.lds, st, x, (const uint4 *)Wq, shift, y, Cin, Cout, T, V, pl.rows, \
-                           pl.tiles_per_clip, ntiles, act_lo, opt);                                               \
+                           pl.tiles_per_clip, ntiles, act_lo, opt, nullptr);                                      \
     } while (0)
     if (terms == 3) { if (bf16out) LAUNCH_T6(3, true); else LAUNCH_T6(3, false); }
     else { if (bf16out) LAUNCH_T6(1, true); else LAUNCH_T6(1, false); }

@@ -76,6 +76,10 @@ typedef enum {
  * outside the kernel run the three-bf16 kernels.  The flag must be the same in stgcn_stem_prep_bytes / _prepare /
  * _ws_bytes / _attention / _tail (the prep blob carries a third weight packing, the workspace a per-clip bound). */
 #define STGCN_STEM_F16MX 0x400u
+/* stgcn_tcn_forward[_packed] with STGCN_MATH_F32_VALU: the 1-D convolution runs along the JOINT axis (Unit2D(dim=3),
+ * model/net.py:28-36: kernel (1,K), padding (0,pad), stride (1,stride)); y is (N,Cout,T,V_out), V_out = (V+2*pad-K)/stride+1.
+ * Inference only; no reference model builds this variant (plain-FMA kernel). */
+#define STGCN_CONV_ALONG_V 0x800u
 
 int stgcn_version(void);
 const char *stgcn_last_error(void);

@@ -497,6 +497,20 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int i = 0; i < MAXB; ++i) acc[s][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // weight fragments and biases of this wave's row block for one subset
+    float wf[KS], bias[4];
+    auto load_w = [&](int s) __attribute__((always_inline)) {
+        const int rb = wave % R8, row = rb * 16 + l16;
+        const float *wr = row < inter_c ? Wa + ((size_t)s * inter_c + row) * Cin : Wb + ((size_t)s * inter_c + row - inter_c) * Cin;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[ks] = ks < ks_n ? wr[4 * ks + lq] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rb * 16 + 4 * lq + i;
+            bias[i] = r < inter_c ? ba[s * inter_c + r] : bb[s * inter_c + r - inter_c];
+        }
+    };
+    load_w(only >= 0 ? only : 0);
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int tc = min(TC, T - t0), px = tc * V, npb = (px + 15) / 16;
         __syncthreads();
@@ -536,20 +550,9 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
         for (int s = 0; s < 3; ++s) {
             if (s < S && (only < 0 || s == only)) {
                 __syncthreads();                        // Xs ready; the previous subset's Gram is done with Es
-                // ---- embeddings
-                for (int rb = wave % R8; rb < nrb; rb += R8) {
-                    const int row = rb * 16 + l16;
-                    const float *wr = row < inter_c ? Wa + ((size_t)s * inter_c + row) * Cin
-                                                    : Wb + ((size_t)s * inter_c + row - inter_c) * Cin;
-                    float wf[KS];
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) wf[ks] = ks < ks_n ? wr[4 * ks + lq] : 0.f;
-                    float bias[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = rb * 16 + 4 * lq + i;
-                        bias[i] = r < inter_c ? ba[s * inter_c + r] : bb[s * inter_c + r - inter_c];
-                    }
+                // ---- embeddings (this wave's row block: nrb <= 8, so exactly one; its fragments were fetched a phase ahead)
+                {
+                    const int rb = wave % R8;
                     for (int pb = wave / R8; pb < npb; pb += pstep) {
                         const int p = pb * 16 + l16;
                         const float *xb = Xs + lq * PXC + (p < px ? p : 0);
@@ -566,6 +569,9 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
                         for (int i = 0; i < 4; ++i) Es[(rb * 16 + 4 * lq + i) * PXC + p] = e4[i] + bias[i];
                     }
                 }
+                // the fragments of the NEXT embedding phase (next subset, or the first one of the next chunk): in flight during
+                // this subset's Gram — fetched at the head of a phase they were 16 - 64 exposed global loads per chunk and subset
+                load_w(only >= 0 ? only : (s + 1 < S ? s + 1 : 0));
                 __syncthreads();
                 // ---- Gram: unit = (block, K part)
                 const float *As = Es, *Bs = Es + (size_t)inter_c * PXC;

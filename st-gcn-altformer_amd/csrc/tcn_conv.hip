@@ -88,6 +88,39 @@ __global__ __launch_bounds__(256) void tcn_valu_kernel(const float *__restrict__
             store_out<BF16OUT>(y, ((size_t)n * Cout + o0 + j) * Tout * V + q, fmaxf(acc[j] + shift[o0 + j], lo));
 }
 
+// The same along the JOINT axis (Unit2D(dim=3), model/net.py:28-36: Conv2d kernel (1,K), padding (0,pad), stride (1,stride)):
+// y[n][o][t][w] = relu( sum_{c,k} Wp[o][c][k] * x[n][c][t][w*stride + k - pad] + shift[o] ),  w < Vout.  Read in place — the
+// module used to transpose into a contiguous copy, run the frame-axis kernel and transpose back.
+template <bool BF16OUT>
+__global__ __launch_bounds__(256) void tcn_valu_joint_axis_kernel(const float *__restrict__ x, const float *__restrict__ Wp,
+                                                                  const float *__restrict__ shift, void *y, int Cin, int Cout,
+                                                                  int T, int V, int K, int stride, int Vout, float lo) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int o0 = blockIdx.y * OBV;
+    const int n = blockIdx.z;
+    if (q >= T * Vout) return;
+    const int pad = (K - 1) / 2;
+    const int t = q / Vout, w = q - t * Vout;
+    float acc[OBV];
+#pragma unroll
+    for (int j = 0; j < OBV; ++j) acc[j] = 0.f;
+    const float *xn = x + (size_t)n * Cin * T * V + (size_t)t * V;
+    for (int c = 0; c < Cin; ++c) {
+        for (int k = 0; k < K; ++k) {
+            const int vi = w * stride + k - pad;
+            if (vi < 0 || vi >= V) continue;
+            const float xv = xn[(size_t)c * T * V + vi];
+#pragma unroll
+            for (int j = 0; j < OBV; ++j)
+                if (o0 + j < Cout) acc[j] = fmaf(Wp[((size_t)(o0 + j) * Cin + c) * K + k], xv, acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < OBV; ++j)
+        if (o0 + j < Cout)
+            store_out<BF16OUT>(y, ((size_t)n * Cout + o0 + j) * T * Vout + q, fmaxf(acc[j] + shift[o0 + j], lo));
+}
+
 // ---------------------------------------------------------------------------------------
 // weight packing
 //   VALU : Wp[o][c][k]                                        = scale[o]*W[o][c][k]
@@ -518,6 +551,21 @@ int launch_tcn(const float *x, const void *Wp, const float *shift, void *y, int 
     const bool bf16out = (flags & STGCN_OUT_BF16) != 0;
     const float lo = (flags & STGCN_RAW) ? -__builtin_huge_valf() : 0.f;  // raw = pre-activation (training-mode BN)
     const int pad = (K - 1) / 2;
+    if (flags & STGCN_CONV_ALONG_V) {      // Unit2D(dim=3): the joint axis
+        if (math != STGCN_MATH_F32_VALU) return fail(STGCN_ERR_UNSUPPORTED, "tcn: STGCN_CONV_ALONG_V goes with STGCN_MATH_F32_VALU");
+        const int Vout = (V + 2 * pad - K) / stride + 1;
+        if (Vout < 1) return fail(STGCN_ERR_ARG, "tcn: V=%d K=%d stride=%d gives no output joint", V, K, stride);
+        if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "tcn: N=%d > 65535 clips per call", N);
+        const dim3 gridv(ceil_div(T * Vout, 256), ceil_div(Cout, OBV), N);
+        if (bf16out)
+            hipLaunchKernelGGL((tcn_valu_joint_axis_kernel<true>), gridv, dim3(256), 0, st, x, (const float *)Wp, shift, y, Cin, Cout,
+                               T, V, K, stride, Vout, lo);
+        else
+            hipLaunchKernelGGL((tcn_valu_joint_axis_kernel<false>), gridv, dim3(256), 0, st, x, (const float *)Wp, shift, y, Cin, Cout,
+                               T, V, K, stride, Vout, lo);
+        STGCN_LAUNCH_CHECK("tcn_valu_joint_axis_kernel");
+        return STGCN_OK;
+    }
     const int Tout = (T + 2 * pad - K) / stride + 1;
     if (Tout < 1) return fail(STGCN_ERR_ARG, "tcn: T=%d K=%d stride=%d gives no output frame", T, K, stride);
     if (N > 65535) return fail(STGCN_ERR_UNSUPPORTED, "tcn: N=%d > 65535 clips per call", N);

@@ -27,6 +27,7 @@ OUT_NTVC = 0x80   # stem entry points: out is (N,T,V,C)
 EMBED_TS = 0x100  # stgcn_patch_embed: rows ordered (clip, joint, frame)
 BN_FROZEN = 0x200  # training entry points: BatchNorm on its running statistics (eval mode under autograd)
 STEM_F16MX = 0x400  # stem entry points, with MATH_BF16X3: fp16 x fp16 + two scaled-e4m3 residual products where KF7 covers the shape
+CONV_ALONG_V = 0x800  # stgcn_tcn_forward[_packed], MATH_F32_VALU: convolve along the joint axis (Unit2D(dim=3))
 MATH_F16MX = MATH_BF16X3 | STEM_F16MX   # as a "math mode" of the modules: bf16x3 everywhere, KF7 in the fused stem
 
 STATUS = {0: "STGCN_OK", -1: "STGCN_ERR_ARG", -2: "STGCN_ERR_UNSUPPORTED",

@@ -115,17 +115,23 @@ def tcn_pack(W, scale, math=MATH_F32) -> torch.Tensor:
     return Wp
 
 
-def tcn_forward_packed(x, Wp, shift, Cout, K, stride=1, math=MATH_F32, out_bf16=False) -> torch.Tensor:
+def tcn_forward_packed(x, Wp, shift, Cout, K, stride=1, math=MATH_F32, out_bf16=False, along_v=False) -> torch.Tensor:
+    """``along_v``: Unit2D(dim=3) (model/net.py:28-36) — the convolution runs along the joint axis of x (N,Cin,T,V), read in
+    place; MATH_F32_VALU packing only; returns (N,Cout,T,V_out)."""
     dev = x.device
     N, Cin, T, V = x.shape
-    Tout = tcn_out_frames(T, K, stride)
-    if Tout < 1:
-        raise ValueError(f"temporal conv: T={T}, K={K}, stride={stride} leaves no output frame")
-    y = torch.empty(N, Cout, Tout, V, device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    Lout = tcn_out_frames(V if along_v else T, K, stride)
+    if Lout < 1:
+        raise ValueError(f"1-D conv: length {V if along_v else T}, K={K}, stride={stride} leaves no output position")
+    if along_v and math != MATH_F32_VALU:
+        raise ValueError("tcn_forward_packed(along_v=True) needs the MATH_F32_VALU packing")
+    shape = (N, Cout, T, Lout) if along_v else (N, Cout, Lout, V)
+    y = torch.empty(*shape, device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    fl = _flags(math, out_bf16) | (_capi.CONV_ALONG_V if along_v else 0)
     with torch.cuda.device(dev):
         _capi.call("stgcn_tcn_forward_packed", _dev_ptr(x, "x", dev), c_void_p(Wp.data_ptr()),
                    _dev_ptr(shift, "shift", dev), c_void_p(y.data_ptr()), c_int(N), c_int(Cin), c_int(Cout),
-                   c_int(T), c_int(V), c_int(K), c_int(stride), c_uint(_flags(math, out_bf16)), _stream(dev))
+                   c_int(T), c_int(V), c_int(K), c_int(stride), c_uint(fl), _stream(dev))
     return y
 
 

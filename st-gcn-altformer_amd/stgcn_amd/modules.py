@@ -543,19 +543,25 @@ class Unit2D(nn.Module):
         _check_input(self, x, backward_ok=self.dim == 2, bn_training=bn_training)
         if x.shape[1] != self.conv.in_channels:
             raise RuntimeError(f"Unit2D: expected {self.conv.in_channels} input channels, got {x.shape[1]}")
-        if self.dim == 3:
-            x = x.transpose(2, 3)
         x = x.contiguous()
         N, Cin, T, V = x.shape
         mode = self.math_mode
-        if mode != MATH_F32_VALU and not F.tcn_supported(Cin, self.conv.out_channels, T, V, self.kernel_size,
-                                                         self.stride, mode):
+        if self.dim == 3:                    # conv along the joints (model/net.py:28-36), read in place by the plain-FMA kernel
+            mode = MATH_F32_VALU
+        elif mode != MATH_F32_VALU and not F.tcn_supported(Cin, self.conv.out_channels, T, V, self.kernel_size,
+                                                           self.stride, mode):
             mode = MATH_F32_VALU
         if self.dropout.p > 0 and self.dropout.training:
             x = self.dropout(x)              # torch's RNG-driven op (the stem always uses p = 0, model/net.py:45)
         wants = _wants_grad(self, x)
         if bn_training or wants:             # (eval mode under autograd: the same kernels on the running statistics)
             bn = self.bn
+            if self.dim == 3:                # batch statistics over a joint-axis conv (no model builds it): the frame-axis
+                x = x.transpose(2, 3).contiguous()   # kernels on the transposed copy; inference reads x in place (below)
+                mode = self.math_mode
+                if mode != MATH_F32_VALU and not F.tcn_supported(Cin, self.conv.out_channels, V, T, self.kernel_size,
+                                                                 self.stride, mode):
+                    mode = MATH_F32_VALU
             if bn_training and (bn.momentum is None or not bn.track_running_stats):
                 raise NotImplementedError("Unit2D: training-mode BatchNorm needs momentum and running statistics")
             if not bn_training and not bn.track_running_stats:
@@ -572,12 +578,12 @@ class Unit2D(nn.Module):
             if bn_training:
                 with torch.no_grad():
                     bn.num_batches_tracked += 1
+            if self.dim == 3:
+                y = y.transpose(2, 3).contiguous()
         else:
             st = self._staged(x.device)
             y = F.tcn_forward_packed(x, self._packed(st, mode), st["shift"], self.conv.out_channels,
-                                     self.kernel_size, self.stride, mode, self.out_bf16)
-        if self.dim == 3:
-            y = y.transpose(2, 3).contiguous()
+                                     self.kernel_size, self.stride, mode, self.out_bf16, along_v=self.dim == 3)
         if self.channels_last_out:           # (only the fused stem writes this layout natively)
             y = y.contiguous(memory_format=torch.channels_last)
         return y

@@ -210,20 +210,32 @@ def test_tcn_vs_oracle_shapes(cin, cout, K, stride, T, V, math, dev):
     parity_gate(y, ref, 1e-4, f"tcn {cin}->{cout} K{K} s{stride} {math}")
 
 
-def test_unit2d_dim3(dev):
-    """dim=3 (conv along joints) = the same op on the (T,V)-transposed tensor."""
+@pytest.mark.parametrize("cin,cout,K,stride,N,T,V", [(32, 128, 3, 1, 2, 10, 22), (3, 70, 9, 1, 3, 7, 46), (16, 16, 5, 2, 2, 5, 25),
+                                                     (8, 40, 1, 1, 1, 300, 3)])
+def test_unit2d_dim3(cin, cout, K, stride, N, T, V, dev):
+    """dim=3 (model/net.py:28-36: conv along the joints) = the same op on the (T,V)-transposed tensor.  Inference reads x in
+    place (STGCN_CONV_ALONG_V, plain-FMA kernel — round 2 transposed into a copy and back); with batch statistics the module
+    still runs the frame-axis kernels on a transposed copy (no model builds either)."""
     from stgcn_amd import Unit2D
     from oracle import stgcn_oracle as so
-    torch.manual_seed(9)
-    m = Unit2D(32, 128, kernel_size=3, dim=3)
-    x = torch.randn(2, 32, 10, 22)
+    torch.manual_seed(9 + K)
+    m = Unit2D(cin, cout, kernel_size=K, stride=stride, dim=3)
+    with torch.no_grad():
+        m.bn.running_mean.normal_(0, 0.3); m.bn.running_var.uniform_(0.5, 2.0); m.bn.weight.uniform_(0.5, 1.5); m.bn.bias.normal_(0, 0.2)
+    x = torch.randn(N, cin, T, V)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     sd["conv.weight"] = sd["conv.weight"].permute(0, 1, 3, 2)        # (Cout,Cin,1,K) -> (Cout,Cin,K,1)
-    tp = so.tcn_params_from_state(sd).to(torch.float64)
+    tp = so.tcn_params_from_state(sd, stride=stride).to(torch.float64)
     ref = so.tcn_forward(x.double().transpose(2, 3), tp).transpose(2, 3)
+    m = m.to(dev)
     with torch.no_grad():
-        y = m.to(dev).eval()(x.to(dev))
-    parity_gate(y, ref, 1e-4, "dim=3")
+        y = m.eval()(x.to(dev))
+    assert y.shape == ref.shape and y.is_contiguous()
+    parity_gate(y, ref, 1e-4, "dim=3, inference")
+    with torch.no_grad():
+        yt = m.train()(x.to(dev))
+    ref_t = so.tcn_forward(x.double().transpose(2, 3), tp, training=True).transpose(2, 3)
+    parity_gate(yt, ref_t, 1e-4, "dim=3, batch statistics")
 
 
 # ---------------------------------------------------------------------------------------

@@ -314,6 +314,10 @@ __global__ __launch_bounds__(NT6) void tcn_bf16_v6_kernel(const float *__restric
         }
 
         // ---- epilogue: each 16-channel x 64-pixel block through this wave's 4 KiB staging slice, 16 B per lane ----------
+        // (Round 3 tried the transposed product instead — pixels as the A operand, so that a lane holds four consecutive pixels
+        //  of one channel and stores 16 bytes straight from the accumulators, no staging: parity-green and 3 % SLOWER per
+        //  launch in a same-box A/B.  A store instruction then covers 16 channel rows x 64 bytes instead of 4 rows x 256: the
+        //  epilogue is bound by the cache lines a CU's store path touches (~9 B/clk/CU either way), not by the LDS round trip.)
         float *stg = reinterpret_cast<float *>(stage + wave * EPI6);
         const int qw = g.q0 + wave * 64;
         const bool full = g.q0 + NP6 - 1 <= g.q_last;            // (scalar) every pixel of the tile lies inside the clip

@@ -1006,7 +1006,8 @@ def test_unit_agcn_generic_backward_vs_oracle(cin, cout, N, T, V, want_dx, dev):
     else:
         assert xg.grad is None
     # fixed-order reductions (per-clip slices, K parts): a second run gives the same bits.  (At these sizes each channel's
-    # BatchNorm statistics come from ONE workgroup; above 64 K elements per channel several add their fp64 partial sums
+    # BatchNorm statistics come from ONE workgroup; above 8 K elements per channel (64 K for tensors of a thousand workgroups
+    # and more: bn_chunks, csrc/common.h) several add their fp64 partial sums
     # atomically, in no fixed order — the one reduction of the path that is not bit-reproducible.)
     first = {k: v.clone() for k, v in _agcn_module_grads(gcn).items()}
     for p in gcn.parameters():

@@ -566,7 +566,7 @@ int stgcn_tcn_forward_train(const float *x, const float *W, const float *conv_bi
 #ifdef STGCN_NO_CONV_STATS    /* A/B builds: the separate statistics pass */
     const bool stats_in_conv = false;
 #else
-    const bool stats_in_conv = !frozen && tcn_v6_supported(Cin, Cout, T, V, K, stride, cflags) && !(ablate_mask() & 8192);
+    const bool stats_in_conv = !frozen && tcn_v6_stats_supported(Cin, Cout, T, V, K, stride, cflags) && !(ablate_mask() & 8192);
 #endif
     if (stats_in_conv) {
         STGCN_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 2 * Cout, st));

@@ -173,6 +173,7 @@ int launch_stem_v6(const float *x, bool x_ntvc, const void *pfrag, const void *p
 bool tcn_v4_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
 // ... and in KF6's form (tcn_bf16_v6.hip): one wave per SIMD, pair-order weights (appended to the packed blob by launch_tcn_pack)
 bool tcn_v6_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
+bool tcn_v6_stats_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);   // launch_tcn_v6(..., stats)
 bool tcn_v6_packs(int Cin, int Cout, int K, unsigned math);
 int launch_tcn_pack_pairs_padded(const float *W, const float *scale, void *Wq, int Cin, int Cout, hipStream_t st);
 int launch_tcn_v6(const float *x, const void *Wq, const float *shift, void *y, int N, int Cin, int Cout, int T, int V, int K,

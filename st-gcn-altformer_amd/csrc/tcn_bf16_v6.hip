@@ -458,6 +458,15 @@ bool tcn_v6_supported(int Cin, int Cout, int T, int V, int K, int stride, unsign
     return plan_t6(Cin, Cout, T, V, K, stride, math == STGCN_MATH_BF16X3 ? 3 : 1, pl);
 }
 
+// the STATS form needs 2 KiB of LDS on top (its per-workgroup fp64 sums)
+bool tcn_v6_stats_supported(int Cin, int Cout, int T, int V, int K, int stride, unsigned flags) {
+    const unsigned math = flags & STGCN_MATH_MASK;
+    if ((math != STGCN_MATH_BF16X3 && math != STGCN_MATH_BF16) || (flags & (STGCN_OUT_BF16 | STGCN_OUT_NTVC))) return false;
+    T6Plan pl;
+    return plan_t6(Cin, Cout, T, V, K, stride, math == STGCN_MATH_BF16X3 ? 3 : 1, pl) &&
+           pl.lds + 2 * 128 * sizeof(double) <= (size_t)kLdsBytes;
+}
+
 // true when launch_tcn_pack appends the pair-order copy of the weights for (Cin, Cout, K, math) — shape-independent part
 // of tcn_v6_supported
 bool tcn_v6_packs(int Cin, int Cout, int K, unsigned math) {

@@ -472,12 +472,22 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
     const float *__restrict__ x, const float *__restrict__ A_eff, const float *__restrict__ Wa,
     const float *__restrict__ ba, const float *__restrict__ Wb, const float *__restrict__ bb,
     float *__restrict__ P, int Cin, int T, int V, int inter_c, int S, int TC, int PXC, int xsc, int xsp,
-    float *__restrict__ xcopy) {
+    float *__restrict__ xcopy, unsigned long long *dbg) {
+#ifdef STGCN_ABLATION   // per-wave phase clocks (diagnostic builds; tools/stamps_k1g.py): 0 staging, 1 barrier waits, 2 embeddings,
+                        // 3 Gram, 4 tail (K-part sums, soft-max, store), 5 whole kernel
+#define KG_STAMP(var) unsigned long long var = 0; if (dbg) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); }
+#define KG_ACC(slot, a, b) if (dbg) { tsum[slot] += (b) - (a); }
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};
+#else
+#define KG_STAMP(var)
+#define KG_ACC(slot, a, b)
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, lq = lane >> 4;
     const int n = blockIdx.x;
+    KG_STAMP(t_begin)
     // gridDim.y == S: one workgroup per (clip, subset) — batches with fewer clips than CUs (the deeper layers' 64-clip steps
     // ran on 64 of 256 CUs); x is then staged once per subset (from L2 for the second and third).  gridDim.y == 1: all subsets.
     const int only = gridDim.y > 1 ? (int)blockIdx.y : -1;
@@ -498,12 +508,27 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
 #pragma unroll
         for (int i = 0; i < MAXB; ++i) acc[s][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // weight fragments and biases of this wave's row block for one subset
+    // Channel c sits in LDS row rho(c) = c with its two low 2-bit fields swapped (C_in % 16 == 0): k-step ks = 4j + i of lane
+    // group lq then multiplies channel 16j + 4lq + i, so a lane's fragments of four k-steps are ONE 16-byte load of its weight
+    // row (16 instead of 64 load instructions per lane at 256 channels; as dwords — 16 rows x 16 bytes per instruction — their
+    // issue alone was a third of the kernel), and the B reads keep the conflict-free row 4 ks + lq.
+    const bool perm = (Cin & 15) == 0;
+    auto rho = [&](int c) { return perm ? ((c & ~15) | ((c & 3) << 2) | ((c >> 2) & 3)) : c; };
     float wf[KS], bias[4];
     auto load_w = [&](int s) __attribute__((always_inline)) {
         const int rb = wave % R8, row = rb * 16 + l16;
         const float *wr = row < inter_c ? Wa + ((size_t)s * inter_c + row) * Cin : Wb + ((size_t)s * inter_c + row - inter_c) * Cin;
+        if (perm) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wf[ks] = ks < ks_n ? wr[4 * ks + lq] : 0.f;
+            for (int j = 0; j < KS / 4; ++j) {
+                const f32x4 w4 = 16 * j < Cin ? *reinterpret_cast<const f32x4 *>(wr + 16 * j + 4 * lq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[4 * j + i] = w4[i];
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf[ks] = ks < ks_n ? wr[4 * ks + lq] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = rb * 16 + 4 * lq + i;
@@ -511,59 +536,122 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
         }
     };
     load_w(only >= 0 ? only : 0);
+    // x of the NEXT chunk travels HBM -> registers while this chunk is multiplied (the staging was 23 - 40 % of the kernel once
+    // the embeddings were fixed: tools/stamps_k1g.py): row wave + 8 r, pixels lane + 64 q.  The register tile is sized for the
+    // chunks the LDS budget gives at C_in = 4 KS (many rows <-> few pixels); other shapes stage in place as before.
+    // (KS = 64 — 256 channels, 44-pixel chunks — stays with in-place staging: its 32 extra registers spilled.)
+    constexpr int RW = KS == 64 ? 1 : KS / 2, QM = KS == 16 ? 6 : (KS == 32 ? 3 : 1);
+    const bool pre = KS != 64 && Cin <= 8 * RW && TC * V <= 64 * QM;
+    float xr[RW][QM];
+    auto xfetch = [&](int t0f) __attribute__((always_inline)) {
+        const int pxf = min(TC, T - t0f) * V;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int k = wave + 8 * r;
+            const float *xrow = xn + (size_t)k * xsc + (size_t)t0f * V * xsp;
+#pragma unroll
+            for (int q = 0; q < QM; ++q) {
+                const int p = lane + 64 * q;
+                xr[r][q] = (k < Cin && p < pxf) ? xrow[(size_t)p * xsp] : 0.f;
+            }
+        }
+    };
+    if (pre) xfetch(0);
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int tc = min(TC, T - t0), px = tc * V, npb = (px + 15) / 16;
+        KG_STAMP(t_b0)
         __syncthreads();
-        // a wave per channel row, lanes along the pixels: no index division.  Two rows x four 64-pixel pieces per trip, all
-        // eight loads issued before the first LDS store (one load per trip left the whole staging — 48 trips per chunk at 64
-        // channels — a chain of exposed memory round trips: most of this kernel's time at small batches)
-        for (int k = wave; k < Cin; k += 16) {
-            const bool two = k + 8 < Cin;
-            const float *xr0 = xn + (size_t)k * xsc + (size_t)t0 * V * xsp;
-            const float *xr1 = xr0 + (size_t)8 * xsc;
-            for (int p0 = lane; p0 < px; p0 += 256) {
-                float v0[4], v1[4];
+        KG_STAMP(t_s0)
+        KG_ACC(1, t_b0, t_s0)
+        if (pre) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int p = p0 + 64 * q;
-                    v0[q] = p < px ? xr0[(size_t)p * xsp] : 0.f;
-                    v1[q] = (two && p < px) ? xr1[(size_t)p * xsp] : 0.f;
-                }
+            for (int r = 0; r < RW; ++r) {
+                const int k = wave + 8 * r;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int p = p0 + 64 * q;
-                    if (p < px) {
-                        Xs[k * PXC + p] = v0[q];
-                        if (two) Xs[(k + 8) * PXC + p] = v1[q];
-                        if (xcopy) {
-                            xcopy[((size_t)n * Cin + k) * T * V + (size_t)t0 * V + p] = v0[q];
-                            if (two) xcopy[((size_t)n * Cin + k + 8) * T * V + (size_t)t0 * V + p] = v1[q];
-                        }
+                for (int q = 0; q < QM; ++q) {
+                    const int p = lane + 64 * q;
+                    if (k < Cin && p < px) {
+                        Xs[rho(k) * PXC + p] = xr[r][q];
+                        if (xcopy) xcopy[((size_t)n * Cin + k) * T * V + (size_t)t0 * V + p] = xr[r][q];
                     }
                 }
             }
+            if (t0 + TC < T) xfetch(t0 + TC);
+        } else {
+        // a wave per channel row, lanes along the pixels: no index division.  RB rows x QP 64-pixel pieces per trip, all RB*QP
+        // loads issued before the first LDS store: one load per trip left the whole staging a chain of exposed memory round
+        // trips — 32 per chunk at 256 channels, where a chunk is two frames (44 pixels: one piece per row) and the chunks are
+        // many: 36 of that kernel's 40 us per chunk.  Few pixels per chunk -> many rows per trip.
+        auto stage = [&](auto rb_c, auto qp_c) __attribute__((always_inline)) {
+            constexpr int RB = decltype(rb_c)::value, QP = decltype(qp_c)::value;
+            for (int k = wave; k < Cin; k += 8 * RB) {
+                for (int p0 = lane; p0 < px; p0 += 64 * QP) {
+                    float v[RB][QP];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const float *xr = xn + (size_t)(k + 8 * r) * xsc + (size_t)t0 * V * xsp;
+#pragma unroll
+                        for (int q = 0; q < QP; ++q) {
+                            const int p = p0 + 64 * q;
+                            v[r][q] = (k + 8 * r < Cin && p < px) ? xr[(size_t)p * xsp] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int q = 0; q < QP; ++q) {
+                            const int p = p0 + 64 * q, kk = k + 8 * r;
+                            if (kk < Cin && p < px) {
+                                Xs[rho(kk) * PXC + p] = v[r][q];
+                                if (xcopy) xcopy[((size_t)n * Cin + kk) * T * V + (size_t)t0 * V + p] = v[r][q];
+                            }
+                        }
+                }
+            }
+        };
+        if (px <= 64) stage(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
+        else if (px <= 128) stage(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+        else stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
         }
+        KG_STAMP(t_s1)
+        KG_ACC(0, t_s0, t_s1)
         // contraction index of the Gram: idx = t * inter_c + c (inter_c is a power of two: shifts, no table)
         const int nk = inter_c * tc;
         const int kpp = ((nk / 4 + KSP - 1) / KSP);     // k-steps per K part  (inter_c % 8 == 0: nk % 4 == 0)
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (s < S && (only < 0 || s == only)) {
+                KG_STAMP(t_b1)
                 __syncthreads();                        // Xs ready; the previous subset's Gram is done with Es
+                KG_STAMP(t_e00)
+                KG_ACC(1, t_b1, t_e00)
+#ifdef STGCN_ABLATION
+                if (dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // price the wait for the prefetched fragments apart
+#endif
+                KG_STAMP(t_e0)
+                KG_ACC(4, t_e00, t_e0)
                 // ---- embeddings (this wave's row block: nrb <= 8, so exactly one; its fragments were fetched a phase ahead)
                 {
                     const int rb = wave % R8;
                     for (int pb = wave / R8; pb < npb; pb += pstep) {
                         const int p = pb * 16 + l16;
-                        const float *xb = Xs + lq * PXC + (p < px ? p : 0);
-                        const bool pok = p < px;
+                        const float *xb = Xs + lq * PXC + (p < px ? p : 0);     // (columns >= px: computed, never read)
                         f32x4 e4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        // eight k-steps per trip: their eight LDS reads in flight, then the MFMAs, and NO branch in between — with
+                        // `if (ks < ks_n)` around every step each step was its own basic block: read, wait out the LDS round
+                        // trip, multiply (285 cycles per step, 68 % of the kernel: tools/stamps_k1g.py).  Steps beyond Cin / 4
+                        // (Cin < 4 KS) read the last valid rows against zero weight fragments.  (Two pixel blocks per trip —
+                        // two accumulator chains, sixteen reads in flight — measured 15 - 20 % slower.)
+                        const int ks_last = ks_n - 1;
 #pragma unroll
-                        for (int ks = 0; ks < KS; ++ks) {
-                            if (ks < ks_n) {
-                                const float b = pok ? xb[(size_t)4 * ks * PXC] : 0.f;
-                                e4 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ks], b, e4, 0, 0, 0);
-                            }
+                        for (int k8 = 0; k8 < KS; k8 += 8) {
+                            float b8[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) b8[q] = xb[(size_t)4 * min(k8 + q, ks_last) * PXC];
+                            __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every read to its MFMA, one register)
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) e4 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[k8 + q], b8[q], e4, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
 #pragma unroll
                         for (int i = 0; i < 4; ++i) Es[(rb * 16 + 4 * lq + i) * PXC + p] = e4[i] + bias[i];
@@ -571,8 +659,16 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
                 }
                 // the fragments of the NEXT embedding phase (next subset, or the first one of the next chunk): in flight during
                 // this subset's Gram — fetched at the head of a phase they were 16 - 64 exposed global loads per chunk and subset
-                load_w(only >= 0 ? only : (s + 1 < S ? s + 1 : 0));
+                KG_STAMP(t_e05)
+                // (one subset per workgroup: the fragments loaded before the first chunk serve every chunk.  Their 64 uncoalesced
+                //  loads per lane — 16 rows x 16 bytes per instruction — took a third of the kernel at 256 channels, as ISSUE time)
+                if (only < 0) load_w(s + 1 < S ? s + 1 : 0);
+                KG_STAMP(t_e1)
+                KG_ACC(2, t_e0, t_e05)
+                KG_ACC(4, t_e05, t_e1)
                 __syncthreads();
+                KG_STAMP(t_g0)
+                KG_ACC(1, t_e1, t_g0)
                 // ---- Gram: unit = (block, K part)
                 const float *As = Es, *Bs = Es + (size_t)inter_c * PXC;
 #pragma unroll
@@ -604,10 +700,13 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
                         }
                     }
                 }
+                KG_STAMP(t_g1)
+                KG_ACC(3, t_g0, t_g1)
             }
         }
     }
     // ---- the K parts of a block meet in LDS (fixed order), soft-max, store
+    KG_STAMP(t_t0)
     __syncthreads();
     const int VV = V * V;
     float *parts = smem;                                // [S][KSP][V][V]
@@ -645,6 +744,15 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
     __syncthreads();
     float *Pn = P + (size_t)n * S * VV;
     for (int e = e_lo + tid; e < e_hi; e += 512) Pn[e] = Sm[e];
+#ifdef STGCN_ABLATION
+    if (dbg) {
+        KG_STAMP(t_end)
+        KG_ACC(4, t_t0, t_end)
+        KG_ACC(5, t_begin, t_end)
+        if (lane == 0 && blockIdx.x < 8 && blockIdx.y == 0)
+            for (int i = 0; i < 6; ++i) dbg[(blockIdx.x * 8 + wave) * 8 + i] = tsum[i];
+    }
+#endif
 }
 
 }  // namespace
@@ -766,7 +874,7 @@ int launch_attention(const float *x, const float *A_eff, const float *Wa, const 
     do {                                                                                                     \
         STGCN_HIP_CHECK(allow_lds((attention_generic_mfma_kernel<KSN, MB>), lds));                           \
         hipLaunchKernelGGL((attention_generic_mfma_kernel<KSN, MB>), dim3(N, N * 2 <= 256 ? S : 1), dim3(512), lds, st, x, A_eff, Wa, ba, Wb, bb, P, \
-                           Cin, T, V, inter_c, S, TC, PXC, xsc, xsp, xcopy);                                 \
+                           Cin, T, V, inter_c, S, TC, PXC, xsc, xsp, xcopy, debug_buffer());                 \
     } while (0)
             if (per_wave <= 1) {
                 if (ks <= 16) LAUNCH_GMFMA(16, 1); else if (ks <= 32) LAUNCH_GMFMA(32, 1); else LAUNCH_GMFMA(64, 1);

@@ -12,12 +12,16 @@ from stgcn_amd import unit_agcn, Unit2D, set_math_mode
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--only", type=int, default=-1); ap.add_argument("--clips", type=int, default=64); ap.add_argument("--frames", type=int, default=90)
+ap.add_argument("--all", action="store_true", help="every unit shape of the ST-TR backbone (ST_TR_new.py:10-16), each at the frame count it sees")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 A = torch.rand(3, 22, 22) * (torch.rand(3, 22, 22) < 0.15)
 res = {}
-for i, (cin, cout, stride) in enumerate(((64, 64, 1), (64, 128, 2))):
+shapes = [(64, 64, 1, a.frames), (64, 128, 2, a.frames)]
+if a.all:
+    shapes += [(128, 128, 1, a.frames // 2), (128, 256, 2, a.frames // 2), (256, 256, 1, (a.frames // 2 + 1) // 2)]
+for i, (cin, cout, stride, frames) in enumerate(shapes):
     if a.only >= 0 and a.only != i:
         continue
     gcn = unit_agcn(cin, cout, A.clone()).to(dev).train()
@@ -25,7 +29,7 @@ for i, (cin, cout, stride) in enumerate(((64, 64, 1), (64, 128, 2))):
     set_math_mode(tcn, "bf16x3")
     with torch.no_grad():
         gcn.bn.weight.fill_(1.0)
-    x = torch.randn(a.clips, cin, a.frames, 22, device=dev).requires_grad_(True)
+    x = torch.randn(a.clips, cin, frames, 22, device=dev).requires_grad_(True)
 
     params = list(gcn.parameters()) + list(tcn.parameters())
     gy = None
@@ -47,5 +51,5 @@ for i, (cin, cout, stride) in enumerate(((64, 64, 1), (64, 128, 2))):
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
-    res[f"unit({cin},{cout},stride {stride})"] = round((time.perf_counter() - t0) / a.steps * 1e3, 3)
+    res[f"unit({cin},{cout},stride {stride})" + (f" T={frames}" if a.all else "")] = round((time.perf_counter() - t0) / a.steps * 1e3, 3)
 print(json.dumps({"what": "TCN_GCN_unit-shaped training step, ms", "clips": a.clips, "T": a.frames, "V": 22, **res}))

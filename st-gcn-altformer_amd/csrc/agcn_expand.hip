@@ -13,6 +13,8 @@
 //    live in registers and every output channel is F FMAs + bias + ReLU, stored coalesced along
 //    the pixel axis (each wave writes 256 contiguous bytes per channel).
 //  * agcn_expand_generic_kernel: any Cin/Cout (used by the deeper TCN_GCN_unit layers).
+#include <type_traits>
+
 #include "common.h"
 
 namespace stgcn {
@@ -264,7 +266,17 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
     const float *__restrict__ bd, const float *__restrict__ Wdown, const float *__restrict__ bdown,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift,
     const float *__restrict__ down_scale, const float *__restrict__ down_shift,
-    float *__restrict__ y, int Cin, int Cout, int T, int V, int TF, int PXP, int mode) {
+    float *__restrict__ y, int Cin, int Cout, int T, int V, int TF, int PXP, int mode, unsigned long long *dbg) {
+#ifdef STGCN_ABLATION   // per-wave phase clocks (diagnostic builds; tools/stamps_k2g.py): 0 x rows -> LDS, 1 barrier waits,
+                        // 2 aggregation, 3 weight fragments, 4 expansion MFMAs, 5 epilogue, 6 whole kernel
+#define KE_STAMP(var) unsigned long long var = 0; if (dbg) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); }
+#define KE_ACC(slot, a, b) if (dbg) { tsum[slot] += (b) - (a); }
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+#define KE_STAMP(var)
+#define KE_ACC(slot, a, b)
+#endif
+    KE_STAMP(t_begin)
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -306,44 +318,94 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
     };
     xfetch(0);
     for (int c0 = 0; c0 < Cin; c0 += 16) {
+        KE_STAMP(t0_)
         __syncthreads();                                    // previous chunk's rows fully consumed (and Ps loaded)
+        KE_STAMP(t1_)
+        KE_ACC(1, t0_, t1_)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) Xs[(wave + 8 * j) * PXP + lane + 64 * q] = xr_[j][q];
         if (c0 + 16 < Cin) xfetch(c0 + 16);
+        KE_STAMP(t2_)
+        KE_ACC(0, t1_, t2_)
         __syncthreads();
-        // ---- aggregation blocks (s, t, w block): rows = the 16 channels
-        for (int u = wave; u < 3 * tf * nvb; u += 8) {
-            const int s = u / (tf * nvb), rem = u - s * tf * nvb, t = rem / nvb, wb = rem - t * nvb;
-            const int w = wb * 16 + l16;
-            f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float *xr = Xs + l16 * PXP + t * V;
-            const float *pr = Ps + s * VV + (w < V ? w : 0);
-            const int nks = (V + 3) / 4;
-            int ks = 0;
-            for (; ks + 4 <= nks; ks += 4) {                // operands of four k-steps ahead of their MFMAs (LDS round trips)
-                float av[4], bv[4];
+        KE_STAMP(t3_)
+        KE_ACC(1, t2_, t3_)
+        // ---- aggregation u_s = x P_s: 16 x 16 blocks (rows = the chunk's 16 channels, columns = a block of joints w) per frame.
+        // A unit = (subset, w block, frame quarter): its P fragments are read ONCE and serve every frame of the quarter and
+        // every k-step count is a compile-time constant of the joint count class — no index division per block, no branch
+        // between a read and its MFMA.  (As one block per trip
+        // with two divisions, per-step tests and a single-step remainder loop this phase cost 390 cycles per MFMA: 24 - 43 %
+        // of the kernel, tools/stamps_k2g.py.)
+        auto aggregate = [&](auto nks_c) __attribute__((always_inline)) {
+            constexpr int NKS = decltype(nks_c)::value;
+            const int npair = 3 * nvb;
+            for (int unit = wave; unit < 4 * npair; unit += 8) {
+                const int fq = unit / npair, pair = unit - fq * npair, s = pair / nvb, wb = pair - s * nvb;
+                const int w = wb * 16 + l16;
+                const bool wok = w < V;
+                float pf[NKS];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int v = 4 * (ks + q) + lq;
-                    av[q] = v < V ? xr[v] : 0.f;
-                    bv[q] = (v < V && w < V) ? pr[v * V] : 0.f;
+                for (int k = 0; k < NKS; ++k) {
+                    const int v = 4 * k + lq;
+                    const float pv = Ps[s * VV + min(v, V - 1) * V + (wok ? w : 0)];
+                    pf[k] = (v < V && wok) ? pv : 0.f;
                 }
+                const float *xrow = Xs + l16 * PXP;
+                for (int t = fq; t < tf; t += 4) {
+                    float af[NKS];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], a4, 0, 0, 0);
-            }
-            for (; ks < nks; ++ks) {
-                const int v = 4 * ks + lq;
-                const float av = v < V ? xr[v] : 0.f;
-                const float bv = (v < V && w < V) ? pr[v * V] : 0.f;
-                a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, a4, 0, 0, 0);
-            }
-            if (w < V) {
+                    for (int k = 0; k < NKS; ++k) {
+                        const int v = 4 * k + lq;
+                        const float xv = xrow[t * V + min(v, V - 1)];
+                        af[k] = v < V ? xv : 0.f;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) Ub[(s * 16 + 4 * lq + i) * PXP + t * V + w] = a4[i];
+                    for (int k = 0; k < NKS; ++k) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], pf[k], a4, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (wok) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) Ub[(s * 16 + 4 * lq + i) * PXP + t * V + w] = a4[i];
+                    }
+                }
+            }
+        };
+        if (V <= 24) {
+            aggregate(std::integral_constant<int, 6>{});
+        } else {     // wider frames: one block per trip, four k-steps at a time (more register-resident operands spill here:
+                     // two workgroups per CU cap this kernel at 128 registers)
+            for (int u = wave; u < 3 * tf * nvb; u += 8) {
+                const int s = u / (tf * nvb), rem = u - s * tf * nvb, t = rem / nvb, wb = rem - t * nvb;
+                const int w = wb * 16 + l16;
+                f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float *xr = Xs + l16 * PXP + t * V;
+                const float *pr = Ps + s * VV + (w < V ? w : 0);
+                const int nks = (V + 3) / 4;
+                for (int ks = 0; ks < nks; ks += 4) {
+                    float av[4], bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int v = 4 * (ks + q) + lq;
+                        const float xv = xr[min(v, V - 1)], pv = pr[min(v, V - 1) * V];
+                        av[q] = v < V ? xv : 0.f;
+                        bv[q] = (v < V && w < V) ? pv : 0.f;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], a4, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (w < V) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Ub[(s * 16 + 4 * lq + i) * PXP + t * V + w] = a4[i];
+                }
             }
         }
+        KE_STAMP(t4_)
+        KE_ACC(2, t3_, t4_)
         // ---- this wave's weight fragments of the chunk (BatchNorm scales folded in)
         float wf[NOW][16];
 #pragma unroll
@@ -356,29 +418,45 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
                 wf[a][ks] = s < 3 ? Wd[((size_t)s * Cout + o) * Cin + c] * sm_ : (identity ? 0.f : Wdown[(size_t)o * Cin + c] * sd_);
             }
         }
+#ifdef STGCN_ABLATION
+        if (dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        KE_STAMP(t5_)
+        KE_ACC(3, t4_, t5_)
         __syncthreads();
+        KE_STAMP(t6_)
+        KE_ACC(1, t5_, t6_)
         // ---- out += A B
 #pragma unroll
         for (int b = 0; b < NPB; ++b) {
             const int pb = pb0 + b * wpo;
             if (pb * 16 < px) {
                 const float *br = Ub + lq * PXP + pb * 16 + l16;
+                // Four k-steps' operands at a time, ONE uniform branch per group (the identity residual has 12 k-steps, the conv
+                // residual 16) and a scheduling fence between the reads and the MFMAs: with a test around every step each step
+                // was its own basic block — read, wait out the LDS round trip, multiply (tools/stamps_k1g.py found the same
+                // pattern costing the attention kernel 68 % of its time).
 #pragma unroll
-                for (int kh = 0; kh < 2; ++kh) {            // eight k-steps' operands at a time (register budget: 128)
-                    float bf[8];
+                for (int kg = 0; kg < 4; ++kg) {
+                    if (16 * kg < KK) {
+                        float bf[4];
 #pragma unroll
-                    for (int k8 = 0; k8 < 8; ++k8) { const int ks = kh * 8 + k8; bf[k8] = (4 * ks < KK) ? br[(size_t)4 * ks * PXP] : 0.f; }
+                        for (int q = 0; q < 4; ++q) bf[q] = br[(size_t)4 * (4 * kg + q) * PXP];
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int a = 0; a < NOW; ++a)
+                        for (int a = 0; a < NOW; ++a)
 #pragma unroll
-                        for (int k8 = 0; k8 < 8; ++k8) {
-                            const int ks = kh * 8 + k8;
-                            if (4 * ks < KK) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[a][ks], bf[k8], acc[a][b], 0, 0, 0);
-                        }
+                            for (int q = 0; q < 4; ++q)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[a][4 * kg + q], bf[q], acc[a][b], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
+        KE_STAMP(t7_)
+        KE_ACC(4, t6_, t7_)
     }
+    KE_STAMP(t_epi)
     // ---- epilogue
     float *yn = y + (size_t)n * Cout * plane + (size_t)t0 * V;
 #pragma unroll
@@ -404,6 +482,15 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
             }
         }
     }
+#ifdef STGCN_ABLATION
+    if (dbg) {
+        KE_STAMP(t_end)
+        KE_ACC(5, t_epi, t_end)
+        KE_ACC(6, t_begin, t_end)
+        if (lane == 0 && blockIdx.x == 0 && blockIdx.y < 8)
+            for (int i = 0; i < 8; ++i) dbg[(blockIdx.y * 8 + wave) * 8 + i] = tsum[i];
+    }
+#endif
 }
 
 }  // namespace
@@ -455,7 +542,7 @@ int launch_agcn_expand(const float *x, const float *P, const float *Wd, const fl
     do {                                                                                                               \
         STGCN_HIP_CHECK(allow_lds((agcn_expand_mfma_kernel<NOW_, NPB_>), lds));                                        \
         hipLaunchKernelGGL((agcn_expand_mfma_kernel<NOW_, NPB_>), grid, dim3(512), lds, st, x, P, Wd, bd, Wdown, bdown, bn_scale, \
-                           bn_shift, down_scale, down_shift, y, Cin, Cout, T, V, TF, PXP, mode);                      \
+                           bn_shift, down_scale, down_shift, y, Cin, Cout, T, V, TF, PXP, mode, debug_buffer());      \
     } while (0)
         if (Cout == 64) LAUNCH_EXP(1, 8);          // 4 o-blocks x 2 waves each: 8 of the 16 pixel blocks per wave
         else if (Cout == 128) LAUNCH_EXP(1, 16);   // 8 o-blocks, one wave each

@@ -23,6 +23,6 @@ os.environ["STGCN_DBG_PTR"] = hex(buf.data_ptr())
 F.agcn_attention(x, A, Wa, ba, Wb, bb); torch.cuda.synchronize()
 t = buf.cpu().view(8, 8, 8).double()
 names = ["staging", "barrier waits", "embeddings", "Gram", "fragments: issue of the next phase's + wait for this one's (+ tail)", "whole kernel"]
-print(f"generic attention, Cin={a.cin} inter_c={ic} T={a.frames} clips={a.clips}: mean over 8 workgroups x 8 waves, s_memtime ticks (100 MHz)")
+print(f"generic attention, Cin={a.cin} inter_c={ic} T={a.frames} clips={a.clips}: mean over 8 workgroups x 8 waves, shader-clock ticks")
 for i, nm in enumerate(names):
     print(f"  {nm:40s} {t[:, :, i].mean():10.0f}   ({100 * t[:, :, i].mean() / t[:, :, 5].mean():5.1f} %)")

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
         // ---- out += A B
 #pragma unroll
         for (int b = 0; b < NPB; ++b) {
-            const int pb = pb0 + b * wpo;
+            const int pb = pb0 * NPB + b;                   // a wave's pixel blocks are CONTIGUOUS (row segments of the epilogue)
             if (pb * 16 < px) {
                 const float *br = Ub + lq * PXP + pb * 16 + l16;
                 // Four k-steps' operands at a time, ONE uniform branch per group (the identity residual has 12 k-steps, the conv
@@ -457,27 +457,71 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
         KE_ACC(4, t6_, t7_)
     }
     KE_STAMP(t_epi)
-    // ---- epilogue
+    // ---- epilogue: + folded constants (+ x for the identity residual), ReLU unless raw.
+    // Even V (every row segment then starts on an 8-byte boundary): each 16-channel x 128-pixel piece of a wave goes through
+    // the wave's own 8 KiB slice of the (now free) operand tiles and leaves as ONE 512-byte row segment per store instruction
+    // (8 bytes per lane) — straight from the accumulators a store covered 4 rows x 64 bytes, 19 - 22 % of the kernel
+    // (tools/stamps_k2g.py).  Odd V keeps the element-wise stores.
     float *yn = y + (size_t)n * Cout * plane + (size_t)t0 * V;
+    auto row_const = [&](int o) {
+        float cst = bn_shift[o], bsum = 0.f;
+        for (int s = 0; s < 3; ++s) bsum += bd[s * Cout + o];
+        cst = fmaf(bn_scale[o], bsum, cst);
+        if (!identity) cst += fmaf(down_scale[o], bdown[o], down_shift[o]);
+        return cst;
+    };
+    if ((V & 1) == 0) {
+        constexpr int SP = 132;                             // slice pitch (floats): 4 rows apart = 16 banks apart
+        __syncthreads();                                    // every wave is past its last read of Ub / Xs
+        float *sl = Ub + wave * 16 * SP;
+        const bool addx = identity && !(mode & 2);
+        const float lo = (mode & 1) ? -__builtin_huge_valf() : 0.f;
 #pragma unroll
-    for (int a = 0; a < NOW; ++a) {
+        for (int a = 0; a < NOW; ++a) {
+            const int o0 = (ob0 + a * ostep) * 16;
+            float cst[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = (ob0 + a * ostep) * 16 + 4 * lq + i;
-            float cst = bn_shift[o];
-            {
-                float b = 0.f;
-                for (int s = 0; s < 3; ++s) b += bd[s * Cout + o];
-                cst = fmaf(bn_scale[o], b, cst);
+            for (int i = 0; i < 4; ++i) cst[i] = row_const(o0 + 4 * lq + i);
+#pragma unroll
+            for (int h = 0; h < NPB / 8; ++h) {             // 8 pixel blocks = 128 pixels per pass
+                const int pbase = (pb0 * NPB + h * 8) * 16;
+                if (pbase < px) {
+#pragma unroll
+                    for (int b8 = 0; b8 < 8; ++b8)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sl[(4 * lq + i) * SP + b8 * 16 + l16] = acc[a][h * 8 + b8][i] + cst[i];
+                    // (same wave writes and reads the slice: program order is enough, no barrier)
+                    const int pp = pbase + 2 * lane;        // this lane's two pixels of every row
+                    if (pp < px) {                          // (px is even)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float2 v = *reinterpret_cast<const float2 *>(sl + r * SP + 2 * lane);
+                            const size_t off = (size_t)(o0 + r) * plane + pp;
+                            if (addx) {
+                                const float2 xv = *reinterpret_cast<const float2 *>(xn + off);
+                                v.x += xv.x; v.y += xv.y;
+                            }
+                            *reinterpret_cast<float2 *>(yn + off) = make_float2(fmaxf(v.x, lo), fmaxf(v.y, lo));
+                        }
+                    }
+                }
             }
-            if (!identity) cst += fmaf(down_scale[o], bdown[o], down_shift[o]);
+        }
+    } else {
 #pragma unroll
-            for (int b = 0; b < NPB; ++b) {
-                const int p = (pb0 + b * wpo) * 16 + l16;
-                if (p < px) {
-                    float val = acc[a][b][i] + cst;
-                    if (identity && !(mode & 2)) val += xn[(size_t)o * plane + p];   // mode bit 1: leave the residual out
-                    yn[(size_t)o * plane + p] = (mode & 1) ? val : fmaxf(val, 0.f);
+        for (int a = 0; a < NOW; ++a) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = (ob0 + a * ostep) * 16 + 4 * lq + i;
+                const float cst = row_const(o);
+#pragma unroll
+                for (int b = 0; b < NPB; ++b) {
+                    const int p = (pb0 * NPB + b) * 16 + l16;
+                    if (p < px) {
+                        float val = acc[a][b][i] + cst;
+                        if (identity && !(mode & 2)) val += xn[(size_t)o * plane + p];   // mode bit 1: leave the residual out
+                        yn[(size_t)o * plane + p] = (mode & 1) ? val : fmaxf(val, 0.f);
+                    }
                 }
             }
         }

@@ -311,7 +311,8 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
     auto xfetch = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float *xr = xn + (size_t)(c0 + wave + 8 * j) * plane;
+            const int r = wave + 8 * j;                     // LDS row r of the chunk holds channel c0 + rho(r): see the weight fragments
+            const float *xr = xn + (size_t)(c0 + (((r & 3) << 2) | (r >> 2))) * plane;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { const int p = lane + 64 * q; xr_[j][q] = p < px ? xr[p] : 0.f; }
         }
@@ -412,10 +413,18 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
         for (int a = 0; a < NOW; ++a) {
             const int o = (ob0 + a * ostep) * 16 + l16;
             const float sm_ = bn_scale[o], sd_ = identity ? 0.f : down_scale[o];
+            // k-step ks = 4 s + j of lane group lq multiplies LDS row 16 s + 4 j + lq, which holds channel c0 + 4 lq + j (the rows
+            // of a chunk are stored with their two 2-bit index fields swapped): a lane's four k-steps of a subset are ONE
+            // 16-byte load of its weight row — as dwords (16 rows x 16 bytes per instruction) the fragments were 9 - 14 % of
+            // the kernel (tools/stamps_k2g.py)
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const int kk = 4 * ks + lq, s = kk >> 4, c = c0 + (kk & 15);
-                wf[a][ks] = s < 3 ? Wd[((size_t)s * Cout + o) * Cin + c] * sm_ : (identity ? 0.f : Wdown[(size_t)o * Cin + c] * sd_);
+            for (int s = 0; s < 4; ++s) {
+                f32x4 w4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (s < 3) w4 = *reinterpret_cast<const f32x4 *>(Wd + ((size_t)s * Cout + o) * Cin + c0 + 4 * lq);
+                else if (!identity) w4 = *reinterpret_cast<const f32x4 *>(Wdown + (size_t)o * Cin + c0 + 4 * lq);
+                const float sc = s < 3 ? sm_ : sd_;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[a][4 * s + j] = w4[j] * sc;
             }
         }
 #ifdef STGCN_ABLATION

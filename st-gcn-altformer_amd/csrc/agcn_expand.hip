@@ -287,7 +287,11 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
     const int VV = V * V, nvb = (V + 15) / 16;
     float *Ps = smem;                       // [3][V][V]
     float *Ub = Ps + 3 * VV;                // [64][PXP]: rows (s, c) for s = 0..2, then the x rows (c)
-    float *Xs = Ub + 48 * PXP;
+    float *Xs = Ub + 48 * PXP;              // [16][PXX]: the aggregation reads these rows as the MFMA's A operand — lanes along
+                                            // the ROWS (one channel per lane), k along the joints: pitch = 4 mod 64 floats puts the
+                                            // 16 rows x 4 k on 64 distinct banks (with the B tiles' pitch, 16 mod 64, the reads
+                                            // were 4-way bank-conflicted)
+    constexpr int PXX = 256 + 4;
     const bool identity = (Wdown == nullptr);
     const int KK = identity ? 48 : 64;      // contraction rows per chunk
     const int nob = Cout / 16;
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Xs[(wave + 8 * j) * PXP + lane + 64 * q] = xr_[j][q];
+            for (int q = 0; q < 4; ++q) Xs[(wave + 8 * j) * PXX + lane + 64 * q] = xr_[j][q];
         if (c0 + 16 < Cin) xfetch(c0 + 16);
         KE_STAMP(t2_)
         KE_ACC(0, t1_, t2_)
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
                     const float pv = Ps[s * VV + min(v, V - 1) * V + (wok ? w : 0)];
                     pf[k] = (v < V && wok) ? pv : 0.f;
                 }
-                const float *xrow = Xs + l16 * PXP;
+                const float *xrow = Xs + l16 * PXX;
                 for (int t = fq; t < tf; t += 4) {
                     float af[NKS];
 #pragma unroll
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
                 const int s = u / (tf * nvb), rem = u - s * tf * nvb, t = rem / nvb, wb = rem - t * nvb;
                 const int w = wb * 16 + l16;
                 f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                const float *xr = Xs + l16 * PXP + t * V;
+                const float *xr = Xs + l16 * PXX + t * V;
                 const float *pr = Ps + s * VV + (w < V ? w : 0);
                 const int nks = (V + 3) / 4;
                 for (int ks = 0; ks < nks; ks += 4) {
@@ -450,7 +454,8 @@ __global__ __launch_bounds__(512, (NOW == 1 ? 4 : 2)) void agcn_expand_mfma_kern
                     if (16 * kg < KK) {
                         float bf[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) bf[q] = br[(size_t)4 * (4 * kg + q) * PXP];
+                        for (int q = 0; q < 4; ++q)          // (kg = 3: the conv residual's x rows, on their own pitch)
+                            bf[q] = kg < 3 ? br[(size_t)4 * (4 * kg + q) * PXP] : Xs[(4 * q + lq) * PXX + pb * 16 + l16];
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int a = 0; a < NOW; ++a)

@@ -681,7 +681,21 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
                         const int va = v < V ? v : 0, wa_ = w < V ? w : 0;
                         const float vm = v < V ? 1.f : 0.f, wm = w < V ? 1.f : 0.f;   // (rows / columns beyond V: zeroed operands)
                         int ks = kq * kpp;
-                        for (; ks + 4 <= k1; ks += 4) {      // four k-steps per trip: eight LDS reads in flight, then the MFMAs
+                        for (; ks + 8 <= k1; ks += 8) {      // eight k-steps per trip: sixteen LDS reads in flight, then the MFMAs
+                            float a8[8], b8[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int idx = 4 * (ks + q) + lq;
+                                const int off = (idx & icm) * PXC + (idx >> icl) * V;
+                                a8[q] = As[off + va] * vm;
+                                b8[q] = Bs[off + wa_] * wm;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a8[q], b8[q], acc[s][i], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        for (; ks + 4 <= k1; ks += 4) {
                             float a4[4], b4[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
@@ -690,8 +704,10 @@ __global__ __launch_bounds__(512) void attention_generic_mfma_kernel(
                                 a4[q] = As[off + va] * vm;
                                 b4[q] = Bs[off + wa_] * wm;
                             }
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q], b4[q], acc[s][i], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                         for (; ks < k1; ++ks) {
                             const int idx = 4 * ks + lq;

@@ -952,7 +952,11 @@ def test_eval_mode_backward_through_the_stem(dev):
     (64, 64, 1, 1, 22, "nctv"),       # a single frame
     (64, 64, 2, 30, 64, "nctv"),      # widest graph the attention kernels take
     (64, 64, 2, 23, 22, "ntvc"),      # channels-last input view
-    (32, 64, 130, 6, 22, "nctv")])    # more than 128 clips: one workgroup per clip (up to 128: one per clip and subset)
+    (32, 64, 130, 6, 22, "nctv"),     # more than 128 clips: one workgroup per clip (up to 128: one per clip and subset)
+    (64, 64, 130, 31, 22, "ntvc"),    # the same from the channels-last view: the contiguous copy is written by the staging path
+    (256, 256, 2, 23, 22, "nctv"),    # 256 channels, two-frame chunks: in-place staging, eight rows per trip
+    (48, 64, 2, 11, 22, "nctv"),      # C_in % 16 == 0 but not a power of two
+    (24, 32, 2, 11, 22, "nctv")])     # C_in % 16 != 0: dword weight fragments, unpermuted rows
 def test_generic_attention_on_matrix_cores_vs_oracle(cin, cout, N, T, V, layout, dev):
     """the adaptive adjacency of the deeper unit_agcn layers (model/unit_agcn.py:73-85 with C_in = 64..256:
     embeddings, Gram over (inter_c, T), column soft-max) runs on the fp32 matrix cores; P and the module output against the

@@ -187,12 +187,14 @@ def main():
     ap.add_argument("--alt-steps", type=int, default=40, help="timed steps of the exact-fp32 block (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=30,
                     help="timed steps of the secondary training block: forward + backward of the stem in .train() (0 = skip)")
+    ap.add_argument("--deeper-steps", type=int, default=20,
+                    help="timed steps of the tertiary block: training step of the two deeper TCN_GCN_unit shapes (0 = skip; 1 GPU only)")
     ap.add_argument("--no-extras", action="store_true", help="headline block only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=32)
     args = ap.parse_args()
     if args.no_extras:
-        args.steady_steps = args.alt_steps = args.train_steps = args.other_steps = 0
+        args.steady_steps = args.alt_steps = args.train_steps = args.other_steps = args.deeper_steps = 0
         args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -426,6 +428,44 @@ def main():
                              "steps": args.train_steps, "warmup": 5, "ms_per_step": round(e4 / args.train_steps * 1e3, 4),
                              "value": round(n_global * args.train_steps / e4, 1), "unit": "clips/s"}
         del g2, t2, Gz
+
+    # ---- tertiary: the deeper layers (model/ST_TR/ST_TR_new.py:355-372) — unit_agcn + Unit2D(k=9) of a
+    #      TCN_GCN_unit, forward + backward WITH the input gradient, 64 clips x 90 frames (the shape DESIGN section 7 tracks) ------
+    if args.deeper_steps > 0 and world == 1 and V == 22:
+        from stgcn_amd import unit_agcn as _agcn, Unit2D as _u2d
+        deeper = {}
+        gA = torch.Generator().manual_seed(7)
+        A3 = torch.rand(3, V, V, generator=gA) * (torch.rand(3, V, V, generator=gA) < 0.15)
+        for cin_, cout_, st_ in ((64, 64, 1), (64, 128, 2)):
+            torch.manual_seed(11)
+            g3 = _agcn(cin_, cout_, A3.clone()).to(dev).train()
+            t3 = _u2d(cout_, cout_, kernel_size=9, stride=st_).to(dev).train()
+            stgcn_amd.set_math_mode(t3, args.math if args.math in ("bf16x3", "bf16", "f32") else "bf16x3")
+            with torch.no_grad():
+                g3.bn.weight.fill_(1.0)
+            x3 = torch.randn(64, cin_, 90, V, device=dev).requires_grad_(True)
+            gy3 = torch.ones_like(t3(g3(x3)).detach())
+            ps3 = list(g3.parameters()) + list(t3.parameters())
+
+            def deep_step():
+                for p_ in ps3:
+                    p_.grad = None
+                x3.grad = None
+                t3(g3(x3)).backward(gy3)
+
+            for _ in range(3):
+                deep_step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.deeper_steps):
+                deep_step()
+            fence()
+            deeper[f"unit({cin_},{cout_},stride {st_})_ms"] = round((time.perf_counter() - t0) / args.deeper_steps * 1e3, 3)
+            del g3, t3, x3, gy3, ps3
+        if rank == 0:
+            line["deeper_layers"] = {"what": "training step (forward + backward with dx) of unit_agcn + Unit2D(k=9) of a "
+                                             "TCN_GCN_unit, 64 clips x 90 frames x 22 joints", "steps": args.deeper_steps,
+                                     "warmup": 3, **deeper}
 
     if rank == 0:
         if cpu_state is not None:

@@ -1066,6 +1066,49 @@ def test_tcn_gcn_unit_trains_end_to_end(dev):
     _grad_gate(xg.grad, grads[-1], 2e-3, "dx of the unit")
 
 
+def test_two_chained_tcn_gcn_units_train(dev):
+    """Two units as the ST-TR backbone chains them (ST_TR_new.py:10-16: (64,64,1) then (64,128,2)), every kernel in its default
+    arithmetic (bf16x3 temporal convs on the one-wave kernels, fp32-MFMA graph convs and GEMM chain): the gradient reaches the
+    FIRST unit's parameters and the chain's input through the second unit's dx, and matches autograd through the fp64 oracle."""
+    from stgcn_amd import Unit2D
+    from oracle import stgcn_oracle as so
+    V = 22
+    g1, _, gp1, _, gen = _random_stem(V, None, 4100, dev, cin=64, c=64)
+    g2, _, gp2, _, _ = _random_stem(V, None, 4101, dev, cin=64, c=128)
+    torch.manual_seed(4102)
+    t1, t2, d2 = Unit2D(64, 64, kernel_size=9), Unit2D(128, 128, kernel_size=9, stride=2), Unit2D(64, 128, kernel_size=1, stride=2)
+    for m, c in ((t1, 64), (t2, 128), (d2, 128)):
+        with torch.no_grad():
+            m.bn.weight.copy_(torch.rand(c, generator=gen) + 0.5)
+            m.bn.bias.copy_(torch.randn(c, generator=gen) * 0.2)
+    tp1 = so.tcn_params_from_state(t1.state_dict()).to(torch.float64)
+    tp2 = so.tcn_params_from_state(t2.state_dict(), stride=2).to(torch.float64)
+    dp2 = so.tcn_params_from_state(d2.state_dict(), stride=2).to(torch.float64)
+    gp1, gp2 = gp1.to(torch.float64), gp2.to(torch.float64)
+    l1 = _agcn_oracle_leaves(gp1)
+    _agcn_oracle_leaves(gp2)
+    tp1.conv_w.requires_grad_(True)
+    x = torch.randn(2, 64, 14, V, generator=gen)
+    xr = x.double().requires_grad_(True)
+    h = so.tcn_forward(so.agcn_forward(xr, gp1, training=True), tp1, training=True) + xr           # unit 1: identity residual
+    yr = so.tcn_forward(so.agcn_forward(h, gp2, training=True), tp2, training=True) + so.tcn_forward(h, dp2, training=True)
+    G = torch.randn(yr.shape, generator=gen)
+    names = sorted(l1)
+    grads = torch.autograd.grad((yr * G.double()).sum(), [l1[k] for k in names] + [tp1.conv_w, xr])
+    for m in (g1, g2):
+        m.train()
+    t1.to(dev).train(); t2.to(dev).train(); d2.to(dev).train()
+    xg = x.to(dev).requires_grad_(True)
+    hg = t1(g1(xg)) + xg
+    y = t2(g2(hg)) + d2(hg)
+    parity_gate(y.detach(), yr.detach(), 2e-4, "two chained units, forward", strict=False)
+    (y * G.to(dev)).sum().backward()
+    # (ReLUs of two units sit under the cotangent: a flipped mask bit moves a gradient by a finite amount)
+    _compare_grads(_agcn_module_grads(g1), dict(zip(names, grads[:len(names)])), 5e-3)
+    _grad_gate(t1.conv.weight.grad.squeeze(-1), grads[-2], 5e-3, "first unit's temporal weights")
+    _grad_gate(xg.grad, grads[-1], 5e-3, "dx of the chain")
+
+
 @pytest.mark.parametrize("math", ["bf16x3", "f32_valu"])
 def test_stem_training_step_vs_oracle(math, dev):
     """loss.backward() through tcn0(gcn0(x)) in .train() (train_sttran.py:185-191): all 4,780 + 147,840 parameter

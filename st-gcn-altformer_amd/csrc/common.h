@@ -214,7 +214,7 @@ bool tcn_wgrad_mfma_supported(int N, int Cin, int Cout, int T, int V, int K, int
 size_t tcn_wgrad_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int stride, unsigned flags);
 // one wave per SIMD, input tile as a ring (tcn_wgrad_v6.hip): 17 <= V <= 24
 bool tcn_wgrad_v6_supported(int N, int Cin, int Cout, int T, int V, int K, int stride);
-int tcn_wgrad_v6_splits(int N, int Cin, int Cout);
+int tcn_wgrad_v6_splits(int N, int Cin, int Cout, int T);
 int launch_tcn_wgrad_v6(const float *dz, const float *x, float *part, int N, int Cin, int Cout, int T, int V, int K, unsigned flags,
                         hipStream_t st);
 int launch_tcn_wgrad(const float *dz, const float *x, float *dW, float *part, int N, int Cin, int Cout, int T, int V, int K,

@@ -618,7 +618,7 @@ size_t tcn_wgrad_ws_bytes(int N, int Cin, int Cout, int T, int V, int K, int str
     if (math == STGCN_MATH_BF16X3 || math == STGCN_MATH_BF16) {
         const WgradPlan pl = plan_wgrad(N, Cin, Cout, T, V, K, stride);
         size_t splits = pl.ok ? (size_t)pl.splits : 0;
-        if (tcn_wgrad_v6_supported(N, Cin, Cout, T, V, K, stride)) splits = std::max(splits, (size_t)tcn_wgrad_v6_splits(N, Cin, Cout));
+        if (tcn_wgrad_v6_supported(N, Cin, Cout, T, V, K, stride)) splits = std::max(splits, (size_t)tcn_wgrad_v6_splits(N, Cin, Cout, T));
         if (splits) return splits * Cout * Cin * K * sizeof(float);
     }
     return 0;
@@ -636,7 +636,7 @@ int launch_tcn_wgrad(const float *dz, const float *x, float *dW, float *part, in
         if (rc != STGCN_OK) return rc;
         const size_t n = (size_t)Cout * Cin * K;
         hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, dW,
-                           tcn_wgrad_v6_splits(N, Cin, Cout), n);
+                           tcn_wgrad_v6_splits(N, Cin, Cout, T), n);
         STGCN_LAUNCH_CHECK("sum_partials_kernel");
         return STGCN_OK;
     }

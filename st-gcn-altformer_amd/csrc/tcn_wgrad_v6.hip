@@ -51,8 +51,9 @@ __device__ __forceinline__ void static_forq(F &&f) {
 template <int TERMS, int NOB>
 __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *__restrict__ dz, const float *__restrict__ x,
                                                                    float *__restrict__ part, int N, int Cin, int Cout, int T,
-                                                                   int V, int K, int cpw /* clips per workgroup */,
-                                                                   unsigned long long *dbg, int dbg_mode) {
+                                                                   int V, int K, int ipw /* items per workgroup */,
+                                                                   int spc /* frame segments per clip */, int Tseg /* frames per
+                                                                   segment, even */, unsigned long long *dbg, int dbg_mode) {
     // (no run-time ablation switches in here: inside the unrolled MFMA groups they tripled the kernel's time; diagnostic
     //  builds can stamp the clock at group boundaries: tools/stamps_wgrad.py)
 #ifdef STGCN_ABLATION
@@ -80,10 +81,13 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
     // LDS: dz tile 0 (hi | lo) | dz tile 1 (hi | lo) | input ring (hi | lo)
     constexpr int AIMG = 128 * WQ_PITCH_A, ATILE = 2 * AIMG, BIMG = 32 * CB * WQ_PITCH_B;
     char *Bring = smq + 2 * ATILE;
-    const int chunks = (T + WQ_TFM - 1) / WQ_TFM;
-    const int upc = chunks + WQ_LEAD;              // units per clip incl. the lead-in
-    const int clip0 = zi * cpw, clip1 = min(clip0 + cpw, N);
-    const int nun = (clip1 > clip0 ? clip1 - clip0 : 0) * upc;     // units of this workgroup
+    // A work ITEM is a frame segment of a clip (spc segments of Tseg frames; spc = 1: the whole clip).  Small batches — the
+    // deeper layers' 64-clip steps put 128 workgroups on 256 CUs — are cut into segments; a segment's lead-in units load the
+    // four frames in front of it (real frames inside the clip, zeros before its first) against a zero dz tile, as a clip's do.
+    const int upc = Tseg / WQ_TFM + WQ_LEAD;       // units per item incl. the lead-in
+    const int items = N * spc;
+    const int clip0 = zi * ipw, clip1 = min(clip0 + ipw, items);        // (item range; the names date from whole-clip items)
+    const int nun = (clip1 > clip0 ? clip1 - clip0 : 0) * upc;         // units of this workgroup
 
     f32x16 acc[NOB][9], acc8[NOB];                // (acc8: tap 8 of the two-block form, kept in VGPRs — see the MFMA loop)
 #pragma unroll
@@ -126,13 +130,15 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
     // unit g of this workgroup -> (clip, first output frame t0; t0 < 0: lead-in)
     // (readfirstlane: the values are uniform, but unless hipcc KNOWS it every buffer load below becomes a waterfall loop over
     //  the lanes' resource descriptors — 129 v_readfirstlane and 32 loops per unit in the first build)
-    auto unit_clip = [&](int g) { return __builtin_amdgcn_readfirstlane(clip0 + g / upc); };
-    auto unit_t0 = [&](int g) { return __builtin_amdgcn_readfirstlane((g % upc - WQ_LEAD) * WQ_TFM); };
+    auto unit_clip = [&](int g) { return __builtin_amdgcn_readfirstlane((clip0 + g / upc) / spc); };
+    auto unit_ts = [&](int g) { return __builtin_amdgcn_readfirstlane(((clip0 + g / upc) % spc) * Tseg); };   // segment's first frame
+    auto unit_t0 = [&](int g) { return __builtin_amdgcn_readfirstlane(unit_ts(g) + (g % upc - WQ_LEAD) * WQ_TFM); };
+    auto unit_dz = [&](int g) { return g % upc >= WQ_LEAD; };           // a lead-in unit multiplies a zero dz tile
     // dz pieces are NOT masked beyond column V: the padded columns of a frame only ever meet the same columns of an input frame,
     // which are zeroed below (what dz holds there is the next row's first pixels or, past the clip, the resource's zeros).
-    auto a_off = [&](int i, bool live, int t0) -> unsigned {
+    auto a_off = [&](int i, bool live, int t0, int te) -> unsigned {    // live: the unit exists and is not a lead-in; te: segment end
         const int t = t0 + a_tt[i];
-        return (live && t0 >= 0 && t < T) ? (unsigned)((((o0 + a_row[i]) * T + t) * V + a_uq[i] * 8) * 4) : OOB;
+        return (live && t < te) ? (unsigned)((((o0 + a_row[i]) * T + t) * V + a_uq[i] * 8) * 4) : OOB;
     };
     auto a_rsrc = [&](int n) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dz + (size_t)n * Cout * T * V), 0, clipA, 0x00020000);
@@ -148,8 +154,8 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off + 4 * j, 0, 0));
     };
-    auto load_a = [&](int i, bool live, int n, int t0) {
-        const unsigned off = a_off(i, live, t0);
+    auto load_a = [&](int i, bool live, int n, int t0, int te) {
+        const unsigned off = a_off(i, live, t0, te);
         load4(&pa[i][0], a_rsrc(n), off);
         load4(&pa[i][4], a_rsrc(n), off + 16);
     };
@@ -202,15 +208,15 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
     __syncthreads();
     if (nun > 0) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) load_a(i, true, unit_clip(0), unit_t0(0));
+        for (int i = 0; i < 3; ++i) load_a(i, unit_dz(0), unit_clip(0), unit_t0(0), min(T, unit_ts(0) + Tseg));
         load_b(true, unit_clip(0), unit_t0(0));
 #pragma unroll
         for (int i = 0; i < 3; ++i) store_a(i, smq);
         store_b(0);
         const bool l1 = 1 < nun;
-        const int n1 = __builtin_amdgcn_readfirstlane(l1 ? unit_clip(1) : clip0), t1 = __builtin_amdgcn_readfirstlane(l1 ? unit_t0(1) : -1);
+        const int n1 = __builtin_amdgcn_readfirstlane(l1 ? unit_clip(1) : 0), t1 = __builtin_amdgcn_readfirstlane(l1 ? unit_t0(1) : -1);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) load_a(i, l1, n1, t1);
+        for (int i = 0; i < 3; ++i) load_a(i, l1 && unit_dz(1), n1, t1, min(T, unit_ts(1) + Tseg));
         load_b(l1, n1, t1);
     }
     __syncthreads();
@@ -224,12 +230,14 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
         b0l[kk] = b0h[kk];
         if constexpr (TERMS == 3) b0l[kk] = *reinterpret_cast<const uint4 *>(Bring + BIMG + b_lane[0] + kk * WQ_FRB);
     }
-    int u2 = 2, c2 = clip0;                       // unit g+2: index within its clip (upc >= 5) and clip — carried, not divided
+    int u2 = 2, c2 = clip0;                       // unit g+2: index within its item (upc >= 5) and item — carried, not divided
     for (int g = 0; g < nun; ++g) {
         WQ_STAMP(t_u0)
         const bool l2 = g + 2 < nun;              // the unit whose loads are issued during this one (all scalar)
         // (readfirstlane: hipcc does not see that the carried counters are uniform — without it every load is a waterfall loop)
-        const int n2 = __builtin_amdgcn_readfirstlane(l2 ? c2 : clip0), t2 = __builtin_amdgcn_readfirstlane(l2 ? (u2 - WQ_LEAD) * WQ_TFM : -1);
+        const int ts2 = __builtin_amdgcn_readfirstlane((c2 % spc) * Tseg), te2 = min(T, ts2 + Tseg);
+        const bool la2 = l2 && u2 >= WQ_LEAD;     // its dz tile is real (not a lead-in)
+        const int n2 = __builtin_amdgcn_readfirstlane(l2 ? c2 / spc : 0), t2 = __builtin_amdgcn_readfirstlane(l2 ? ts2 + (u2 - WQ_LEAD) * WQ_TFM : -1);
         char *acur = smq + (g & 1) * ATILE, *anxt = smq + ((g + 1) & 1) * ATILE;
         // Staging of unit g+1 (convert + LDS stores) and the loads of unit g+2, cut into PIECES of a few instructions that go
         // into the slots after the MFMAs (an MFMA occupies the pipe for 32 cycles; instructions placed right behind it issue
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(WQ_THREADS) void tcn_wgrad_v6_kernel(const float *_
                 if constexpr (r < 8) { if constexpr (r % 2 == 0) pack_hi(pa[i], r / 2, 8); else pack_lo(pa[i], r / 2); }
                 else if constexpr (r == 8) *reinterpret_cast<uint4 *>(anxt + a_lds[i]) = make_uint4(sh[0], sh[1], sh[2], sh[3]);
                 else if constexpr (r == 9) { if constexpr (TERMS == 3) *reinterpret_cast<uint4 *>(anxt + AIMG + a_lds[i]) = make_uint4(sl[0], sl[1], sl[2], sl[3]); }
-                else if constexpr (r == 10) goff = a_off(i, l2, t2);
+                else if constexpr (r == 10) goff = a_off(i, la2, t2, te2);
                 else if constexpr (r == 11) load4(&pa[i][0], ra2, goff);
                 else load4(&pa[i][4], ra2, goff + 16);
             } else if constexpr (P < 3 * PA_N + PB_N * CB) {
@@ -435,28 +443,46 @@ bool tcn_wgrad_v6_supported(int N, int Cin, int Cout, int T, int V, int K, int s
 // two dz blocks per wave (64 input channels per workgroup) where the shape allows  (diagnostic builds: STGCN_ABLATE=4 off)
 static bool wgrad_v6_two_blocks(int Cin, int Cout) { return Cin % 64 == 0 && Cout % 128 == 0 && !(ablate_mask() & 4); }
 
-int tcn_wgrad_v6_splits(int N, int Cin, int Cout) {
+// work items = (clip, frame segment): whole clips when there are enough of them for one workgroup per CU, else segments of at
+// least 16 frames (a segment pays four lead-in units)
+struct WqItems { int splits, spc, Tseg, ipw; };
+static WqItems wgrad_v6_items(int N, int Cin, int Cout, int T) {
     const int wgs = (Cin / (wgrad_v6_two_blocks(Cin, Cout) ? 64 : 32)) * ceil_div(Cout, 128);
-    int splits = 256 / wgs;                       // about one workgroup per CU
-    if (splits < 1) splits = 1;
-    if (splits > N) splits = N;
-    return splits;
+    int want = 256 / wgs;                         // about one workgroup per CU
+    if (want < 1) want = 1;
+    int spc = 1;
+    // (segments only in the one-block form: with two 32-channel blocks per wave the segmented kernel measured 7 % SLOWER on all
+    //  256 CUs than whole clips on 128 — 221 vs 206 us at 128 channels, 64 clips — while the one-block form gained 30 %)
+    if (N < want && !wgrad_v6_two_blocks(Cin, Cout)) {
+        spc = ceil_div(want, N);
+        const int cap = T / 16 > 1 ? T / 16 : 1;
+        if (spc > cap) spc = cap;
+    }
+    WqItems it;
+    it.Tseg = ceil_div(ceil_div(T, spc), WQ_TFM) * WQ_TFM;
+    it.spc = ceil_div(T, it.Tseg);
+    const int items = N * it.spc;
+    it.splits = want < items ? want : items;
+    it.ipw = ceil_div(items, it.splits);
+    it.splits = ceil_div(items, it.ipw);          // (no empty workgroups: every partial slice is written)
+    return it;
 }
+
+int tcn_wgrad_v6_splits(int N, int Cin, int Cout, int T) { return wgrad_v6_items(N, Cin, Cout, T).splits; }
 
 // partial sums: part[splits][Cout][Cin][K] (the caller sums them in a fixed order)
 int launch_tcn_wgrad_v6(const float *dz, const float *x, float *part, int N, int Cin, int Cout, int T, int V, int K, unsigned flags,
                         hipStream_t st) {
     const unsigned math = flags & STGCN_MATH_MASK;
-    const int splits = tcn_wgrad_v6_splits(N, Cin, Cout);
-    const int cpw = ceil_div(N, splits);
+    const WqItems it = wgrad_v6_items(N, Cin, Cout, T);
     const bool two = wgrad_v6_two_blocks(Cin, Cout);
-    const dim3 grid(Cin / (two ? 64 : 32), ceil_div(Cout, 128), splits);
+    const dim3 grid(Cin / (two ? 64 : 32), ceil_div(Cout, 128), it.splits);
     const size_t lds = (size_t)2 * 2 * 128 * WQ_PITCH_A + (size_t)2 * 32 * (two ? 2 : 1) * WQ_PITCH_B;
 #define LAUNCH_WQ(TERMS, NOB)                                                                                         \
     do {                                                                                                              \
         STGCN_HIP_CHECK(allow_lds((tcn_wgrad_v6_kernel<TERMS, NOB>), lds));                                           \
         hipLaunchKernelGGL((tcn_wgrad_v6_kernel<TERMS, NOB>), grid, dim3(WQ_THREADS), lds, st, dz, x, part, N, Cin, Cout, T, V, K, \
-                           cpw, debug_buffer(), (ablate_mask() & 64) ? 1 : 0);                                                                                                    \
+                           it.ipw, it.spc, it.Tseg, debug_buffer(), (ablate_mask() & 64) ? 1 : 0);                                                                                                    \
     } while (0)
     if (math == STGCN_MATH_BF16X3) { if (two) LAUNCH_WQ(3, 2); else LAUNCH_WQ(3, 1); }
     else { if (two) LAUNCH_WQ(1, 2); else LAUNCH_WQ(1, 1); }

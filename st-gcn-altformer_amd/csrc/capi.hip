@@ -397,17 +397,6 @@ static size_t agcn_bwd_small_bytes(int Cout) {
     return align_up((size_t)Cout * 3 * sizeof(double) + (size_t)Cout * 12 * sizeof(float), 256);
 }
 
-// identity residual: g = dy where relu's argument (s_m*zm + t_m) + x was positive  ->  dx (= dL/dx of the "+ x" term)
-__global__ static void identity_residual_grad_kernel(const float *__restrict__ zm, const float *__restrict__ x,
-                                                     const float *__restrict__ sm, const float *__restrict__ tm,
-                                                     const float *__restrict__ dy, float *__restrict__ dx, size_t total,
-                                                     int C, size_t plane) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const int c = (int)((e / plane) % C);
-    dx[e] = (fmaf(zm[e], sm[c], tm[c]) + x[e] > 0.f) ? dy[e] : 0.f;
-}
-
 // The moment-form backward (agcn_backward.hip) serves the stem's shape class after a moments-path forward when no input
 // gradient is wanted; everything else (any Cin / Cout / subsets, identity residual, dx, saved branches) takes the generic
 // GEMM chain.
@@ -513,16 +502,13 @@ int stgcn_agcn_backward_train(const float *x, const float *A_eff, const float *W
     }
     // generic path: materialise both pre-BatchNorm gradients, then the GEMM chain
     float *dzm = (float *)body, *dzd = dzm + total, *gws = dzd + total;
+    // (identity residual, unit_agcn.py:57-58,92: dL/dx of the "+ x" term is the masked cotangent itself — written by the same
+    //  pass as dx's first term; it was a kernel of its own re-reading zm, x and dy)
+    const bool dx_from_g = dx != nullptr && !has_down;
     rc = launch_bn_relu_bwd_apply(zm, sm_, tm_, mean_m, inv_m, zb, sb, tb, mb, ib, dy, coefm, has_down ? coefd : nullptr, dzm,
-                                  has_down ? dzd : nullptr, nullptr, N, Cout, plane, st);
+                                  has_down ? dzd : nullptr, nullptr, N, Cout, plane, st, dx_from_g ? dx : nullptr);
     if (rc != STGCN_OK) return rc;
-    int dx_init = 0;
-    if (dx != nullptr && !has_down) {        // the "+ x" term of unit_agcn.py:57-58,92
-        hipLaunchKernelGGL(identity_residual_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, zm, x, sm_, tm_,
-                           dy, dx, total, Cout, plane);
-        STGCN_LAUNCH_CHECK("identity_residual_grad_kernel");
-        dx_init = 1;
-    }
+    const int dx_init = dx_from_g ? 1 : 0;
     return launch_agcn_bwd_generic(x, P, A_eff, dzm, has_down ? dzd : nullptr, Wa, ba, Wb, bb, Wd, Wdown, gws, dWa, dba, dWb, dbb,
                                    dWd, dbd, dWdown, dbdown, dPA, dx, dx_init, N, Cin, Cout, T, V, inter_c, subsets, st);
 }

@@ -205,7 +205,8 @@ int launch_upsample2(const float *dz, float *dzu, size_t rows, int Tout, int T, 
 int launch_bn_relu_bwd_apply(const float *za, const float *sa, const float *ta, const float *ma, const float *ia,
                              const float *zb, const float *sb, const float *tb, const float *mb, const float *ib,
                              const float *dy, const float *coefa, const float *coefb, float *dza, float *dzb, double *bsum,
-                             int N, int C, size_t plane, hipStream_t st);
+                             int N, int C, size_t plane, hipStream_t st,
+                             float *gout = nullptr);   // optional: the masked cotangent g itself (identity residual: dL/dx of "+ x")
 int launch_doubles_to_floats(const double *src, float *dst, int n, hipStream_t st);
 int launch_weight_flip(const float *W, float *Wf, int Cout, int Cin, int K, hipStream_t st);
 int launch_tcn_dgrad_valu(const float *dz, const float *W, float *dx, int N, int Cin, int Cout, int T, int V, int K,

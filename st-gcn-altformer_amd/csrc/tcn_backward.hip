@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(BnSide a, BnSide
                                                                  const float *__restrict__ coefa,
                                                                  const float *__restrict__ coefb, float *__restrict__ dza,
                                                                  float *__restrict__ dzb, double *__restrict__ bsum, int N,
-                                                                 int C, size_t plane) {
+                                                                 int C, size_t plane, float *__restrict__ gout) {
     const int c = blockIdx.y;
     const ChannelRows it(N, plane);
     const ChanCoef k(a, b, c);
@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(BnSide a, BnSide
     for (int n = it.n_lo; n < it.n_hi; ++n) {
         const size_t base = ((size_t)n * C + c) * plane;
         float a0 = 0.f, a1 = 0.f;
-        auto one = [&](float za, float zb, float d, float &oa, float &ob) {
+        auto one = [&](float za, float zb, float d, float &oa, float &ob, float &og) {
             const float g = k.masked(za, zb, d);
+            og = g;                               // gout: the masked cotangent itself = dL/dx of an identity residual ("+ x")
             oa = ka * (g - c1 - (za - k.ma) * k.ia * c2a);
             a0 += oa;
             if (two) {
@@ -148,18 +149,20 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(BnSide a, BnSide
                 const float4 va = *reinterpret_cast<const float4 *>(a.z + base + p);
                 const float4 vb = k.mode ? *reinterpret_cast<const float4 *>(b.z + base + p) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 vd = *reinterpret_cast<const float4 *>(dy + base + p);
-                float4 oa, ob = make_float4(0.f, 0.f, 0.f, 0.f);
-                one(va.x, vb.x, vd.x, oa.x, ob.x); one(va.y, vb.y, vd.y, oa.y, ob.y);
-                one(va.z, vb.z, vd.z, oa.z, ob.z); one(va.w, vb.w, vd.w, oa.w, ob.w);
+                float4 oa, ob = make_float4(0.f, 0.f, 0.f, 0.f), og;
+                one(va.x, vb.x, vd.x, oa.x, ob.x, og.x); one(va.y, vb.y, vd.y, oa.y, ob.y, og.y);
+                one(va.z, vb.z, vd.z, oa.z, ob.z, og.z); one(va.w, vb.w, vd.w, oa.w, ob.w, og.w);
                 *reinterpret_cast<float4 *>(dza + base + p) = oa;
                 if (two) *reinterpret_cast<float4 *>(dzb + base + p) = ob;
+                if (gout) *reinterpret_cast<float4 *>(gout + base + p) = og;
             }
         } else {
             for (size_t p = threadIdx.x; p < plane; p += 256) {
-                float oa, ob = 0.f;
-                one(a.z[base + p], k.mode ? b.z[base + p] : 0.f, dy[base + p], oa, ob);
+                float oa, ob = 0.f, og;
+                one(a.z[base + p], k.mode ? b.z[base + p] : 0.f, dy[base + p], oa, ob, og);
                 dza[base + p] = oa;
                 if (two) dzb[base + p] = ob;
+                if (gout) gout[base + p] = og;
             }
         }
         s0 += (double)a0;
@@ -567,11 +570,11 @@ int launch_bn_bwd_finalize(const double *sums, int which, double count, const fl
 int launch_bn_relu_bwd_apply(const float *za, const float *sa, const float *ta, const float *ma, const float *ia,
                              const float *zb, const float *sb, const float *tb, const float *mb, const float *ib,
                              const float *dy, const float *coefa, const float *coefb, float *dza, float *dzb, double *bsum,
-                             int N, int C, size_t plane, hipStream_t st) {
+                             int N, int C, size_t plane, hipStream_t st, float *gout) {
     if (bsum) STGCN_HIP_CHECK(hipMemsetAsync(bsum, 0, sizeof(double) * 2 * C, st));
     const BnSide a{za, sa, ta, ma, ia}, b{zb, sb, tb, mb, ib};
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(bn_chunks(N, plane, C), C), dim3(256), 0, st, a, b, dy, coefa,
-                       coefb, dza, dzb, bsum, N, C, plane);
+                       coefb, dza, dzb, bsum, N, C, plane, gout);
     STGCN_LAUNCH_CHECK("bn_relu_bwd_apply_kernel");
     return STGCN_OK;
 }

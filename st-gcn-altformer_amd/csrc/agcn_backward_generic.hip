@@ -107,11 +107,7 @@ int launch_agcn_bwd_generic(const float *x, const float *Pm, const float *A_eff,
     }
     if (dx != nullptr && !dx_initialised) return fail(STGCN_ERR_ARG, "agcn backward: dx has no initial term");
     // ---- u_s = x P_s for every (clip, subset): rows (channel, frame), V x V matrix --------------------------------
-    {
-        GemmArgs g{x, Pm, U, nullptr, R, V, V, V, 1, xs, V, 1, (long long)S * VV, V, 1, (long long)S * xs, 1.f, 0};
-        g.b_inner = S; g.a_sb2 = 0; g.b_sb2 = VV; g.c_sb2 = xs;
-        OK(launch_gemm_f32(g, N * S, st));
-    }
+    OK(launch_rowmix(x, Pm, U, R, V, 1, 0, xs, 0, 0, (long long)S * VV, VV, 0, false, (long long)S * xs, xs, N * S, S, st));
     // dWd_s = sum_n dzm u_s^T ;  dbd_s = sum dzm (the same vector for every subset)
     OK(wgrad(dzm, zs, Cout, U, (long long)S * xs, xs, Cin, S, dWd, dbd, S));
     // ---- du_s = Wd_s^T dzm : A[m = c][k = o] = Wd[s][o][c] -------------------------------------------------------
@@ -121,9 +117,7 @@ int launch_agcn_bwd_generic(const float *x, const float *Pm, const float *A_eff,
         OK(launch_gemm_f32(g, N * S, st));
     }
     if (dx != nullptr) {          // dx += sum_s du_s P_s^T : k = (s, w);  A[m = r][k] = du_s[r][w],  B[k][n = v] = P_s[v][w]
-        GemmArgs g{DU, Pm, dx, nullptr, R, V, S * V, V, xs, (long long)S * xs, VV, V, (long long)S * VV, V, 1, xs, 1.f, 1};
-        g.k_inner = V; g.a_sk2 = 1; g.b_sk2 = 1;
-        OK(launch_gemm_f32(g, N, st));
+        OK(launch_rowmix(DU, Pm, dx, R, V, S, 1, (long long)S * xs, 0, xs, (long long)S * VV, 0, VV, true, xs, 0, N, 0, st));
     }
     // ---- dP_s = x^T du_s (V x V per clip and subset), dPA_s = sum over clips ------------------------------------------
     {
@@ -147,13 +141,8 @@ int launch_agcn_bwd_generic(const float *x, const float *Pm, const float *A_eff,
         OK(launch_gemm_f32(g, N, st));
     }
     // da_s[r][v] = sum_w b_s[r][w] dS_s[v][w] ;  db_s[r][w] = sum_v a_s[r][v] dS_s[v][w]     (rows r = (c', t))
-    {
-        GemmArgs g{EB, DS, DA, nullptr, RI, V, V, V, 1, (long long)S * es, 1, V, (long long)S * VV, V, 1, (long long)S * es, 1.f, 0};
-        g.b_inner = S; g.a_sb2 = es; g.b_sb2 = VV; g.c_sb2 = es;
-        OK(launch_gemm_f32(g, N * S, st));
-        g.A = EA; g.C = DB; g.b_sk = V; g.b_sn = 1;
-        OK(launch_gemm_f32(g, N * S, st));
-    }
+    OK(launch_rowmix(EB, DS, DA, RI, V, 1, 0, (long long)S * es, es, 0, (long long)S * VV, VV, 0, true, (long long)S * es, es, N * S, S, st));
+    OK(launch_rowmix(EA, DS, DB, RI, V, 1, 0, (long long)S * es, es, 0, (long long)S * VV, VV, 0, false, (long long)S * es, es, N * S, S, st));
     // dWa = sum_n da x^T (rows (s, c') stacked: the layout of Wa itself) ;  dba = sum da ;  the same for b
     OK(wgrad(DA, (long long)S * es, SI, x, xs, 0, Cin, 1, dWa, dba, 1));
     OK(wgrad(DB, (long long)S * es, SI, x, xs, 0, Cin, 1, dWb, dbb, 1));

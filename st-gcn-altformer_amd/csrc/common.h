@@ -278,6 +278,10 @@ int launch_gemm_f32(const GemmArgs &g, int batch, hipStream_t st);
 int launch_sum_parts(const float *part, float *out, int parts, size_t n, hipStream_t st, int reps = 1, size_t rep_stride = 0);
 int launch_add_inplace(float *dst, const float *src, size_t n, hipStream_t st);
 int launch_row_sum(const float *in, float *out, int rows, int cols, hipStream_t st);
+// out[b][r][:] (+)= sum_{i < nsum} in[b][i][r][:] . M[b][i]  (rows of V floats times V x V matrices; gemm_f32.hip)
+int launch_rowmix(const float *in, const float *M, float *out, int R, int V, int nsum, int accumulate, long long in_sb,
+                  long long in_sb2, long long in_ss, long long m_sb, long long m_sb2, long long m_ss, bool m_transposed,
+                  long long out_sb, long long out_sb2, int batch, int b_inner, hipStream_t st);
 int launch_softmax_bwd(const float *P, const float *A_eff, const float *dP, float *dS, int N, int V, int S, float alpha,
                        hipStream_t st);
 

@@ -183,6 +183,97 @@ __global__ __launch_bounds__(32 * ROWS) void sum_parts_kernel(const float *__res
     }
 }
 
+// Rows times a small square matrix, the per-frame joint mixing of unit_agcn (model/unit_agcn.py:87-88) and its transposes in
+// the backward:   out[b][r][w] (+)= sum_{i < nsum} sum_v in[b][i][r][v] * M[b][i][v][w]      (V <= 64 joints)
+//   u_s = x P_s;  dx += sum_s du_s P_s^T (nsum = 3, M read transposed);  da = b dS^T;  db = a dS.
+// These are streaming operations — a row of V floats in, a row of V floats out, V^2 FMAs per row — and ran on the generic
+// MFMA GEMM at 40 vector instructions per MFMA (index arithmetic and bounds of a 128 x 32 tile for N = K = 22): 64 us for
+// 128 MB.  Here: 256 rows per workgroup staged through LDS with coalesced 16-byte accesses, one row per thread, the matrices in
+// LDS read as 16-byte broadcasts (every lane the same address), exact fp32 FMAs in the order v = 0, 1, ...
+struct RowMixArgs {
+    const float *in, *M;
+    float *out;
+    int R, V, nsum, accumulate;
+    long long in_sb, in_sb2, in_ss;      // batch (outer, inner) and summand strides of `in` (floats); rows are V contiguous floats
+    long long m_sb, m_sb2, m_ss;         // the same for M
+    int m_sv, m_sw;                      // element strides of M's (v, w): (V, 1) plain, (1, V) transposed
+    long long out_sb, out_sb2;
+    int b_inner;                         // batch b = bq * b_inner + br (0: single level)
+};
+
+template <int VP /* >= V: output columns per thread, 24 / 32 / 48 / 64 */>
+__global__ __launch_bounds__(256) void rowmix_kernel(RowMixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float rm_lds[];
+    float *Ms = rm_lds;                               // [nsum][V][VP]  (row v: the VP outputs' coefficients, zero padded)
+    float *tile = Ms + a.nsum * a.V * VP;             // [256 rows][V] as in memory (+ 4 floats of slack)
+    const int tid = threadIdx.x, V = a.V;
+    const int b = blockIdx.y, bq = a.b_inner ? b / a.b_inner : b, br = a.b_inner ? b - bq * a.b_inner : 0;
+    const int r0 = blockIdx.x * 256, rows = min(256, a.R - r0);
+    const float *Mb = a.M + (size_t)bq * a.m_sb + (size_t)br * a.m_sb2;
+    for (int e = tid; e < a.nsum * V * VP; e += 256) {
+        const int i = e / (V * VP), rem = e - i * V * VP, v = rem / VP, w = rem - v * VP;
+        Ms[e] = w < V ? Mb[(size_t)i * a.m_ss + (size_t)v * a.m_sv + (size_t)w * a.m_sw] : 0.f;
+    }
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    f32x2 acc2[VP / 2];                               // pairs: v_pk_fma_f32 does two FMAs per instruction
+#pragma unroll
+    for (int w = 0; w < VP / 2; ++w) acc2[w] = f32x2{0.f, 0.f};
+    const int n = rows * V;                           // floats of the row block (contiguous in memory)
+    for (int i = 0; i < a.nsum; ++i) {
+        const float *src = a.in + (size_t)bq * a.in_sb + (size_t)br * a.in_sb2 + (size_t)i * a.in_ss + (size_t)r0 * V;
+        __syncthreads();                              // Ms ready / previous summand's tile consumed
+        // (prefetching the next summand's rows into registers — 16 x 16 bytes per thread — measured 1.7x SLOWER: occupancy)
+        if ((((size_t)src) & 15) == 0) {
+            for (int e = tid * 4; e < n; e += 1024) {
+                if (e + 3 < n) *reinterpret_cast<float4 *>(tile + e) = *reinterpret_cast<const float4 *>(src + e);
+                else for (int j = e; j < n; ++j) tile[j] = src[j];
+            }
+        } else {
+            for (int e = tid; e < n; e += 256) tile[e] = src[e];
+        }
+        __syncthreads();
+        if (tid < rows) {
+            const float *row = tile + tid * V;
+            const float *Mi = Ms + i * V * VP;
+            for (int v = 0; v < V; ++v) {
+                const float xv = row[v];
+                const f32x2 x2 = f32x2{xv, xv};
+#pragma unroll
+                for (int w4 = 0; w4 < VP / 4; ++w4) {
+                    const float4 m4 = *reinterpret_cast<const float4 *>(Mi + v * VP + 4 * w4);     // broadcast read
+                    acc2[2 * w4] = __builtin_elementwise_fma(x2, f32x2{m4.x, m4.y}, acc2[2 * w4]);
+                    acc2[2 * w4 + 1] = __builtin_elementwise_fma(x2, f32x2{m4.z, m4.w}, acc2[2 * w4 + 1]);
+                }
+            }
+        }
+    }
+    __syncthreads();                                  // the last tile is consumed: reuse it for the output rows
+    if (tid < rows) {
+        float *row = tile + tid * V;
+#pragma unroll
+        for (int w = 0; w < VP; ++w)
+            if (w < V) row[w] = acc2[w >> 1][w & 1];
+    }
+    __syncthreads();
+    float *dst = a.out + (size_t)bq * a.out_sb + (size_t)br * a.out_sb2 + (size_t)r0 * V;
+    if ((((size_t)dst) & 15) == 0) {
+        for (int e = tid * 4; e < n; e += 1024) {
+            if (e + 3 < n) {
+                float4 v = *reinterpret_cast<const float4 *>(tile + e);
+                if (a.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4 *>(dst + e);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                *reinterpret_cast<float4 *>(dst + e) = v;
+            } else {
+                for (int j = e; j < n; ++j) dst[j] = a.accumulate ? dst[j] + tile[j] : tile[j];
+            }
+        }
+    } else {
+        for (int e = tid; e < n; e += 256) dst[e] = a.accumulate ? dst[e] + tile[e] : tile[e];
+    }
+}
+
 __global__ __launch_bounds__(256) void add_inplace_kernel(float *__restrict__ dst, const float *__restrict__ src, size_t n) {
     const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e + 3 < n) {
@@ -303,6 +394,27 @@ int launch_add_inplace(float *dst, const float *src, size_t n, hipStream_t st) {
 int launch_row_sum(const float *in, float *out, int rows, int cols, hipStream_t st) {
     hipLaunchKernelGGL(row_sum_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, in, out, rows, cols);
     STGCN_LAUNCH_CHECK("row_sum_kernel");
+    return STGCN_OK;
+}
+
+int launch_rowmix(const float *in, const float *M, float *out, int R, int V, int nsum, int accumulate, long long in_sb,
+                  long long in_sb2, long long in_ss, long long m_sb, long long m_sb2, long long m_ss, bool m_transposed,
+                  long long out_sb, long long out_sb2, int batch, int b_inner, hipStream_t st) {
+    if (V < 1 || V > 64 || R < 1 || nsum < 1 || batch < 1) return fail(STGCN_ERR_ARG, "rowmix: V=%d R=%d nsum=%d", V, R, nsum);
+    if (batch > 65535) return fail(STGCN_ERR_UNSUPPORTED, "rowmix: batch %d > 65535", batch);
+    RowMixArgs a{in, M, out, R, V, nsum, accumulate, in_sb, in_sb2, in_ss, m_sb, m_sb2, m_ss, m_transposed ? 1 : V,
+                 m_transposed ? V : 1, out_sb, out_sb2, b_inner};
+    const int VP = V <= 24 ? 24 : (V <= 32 ? 32 : (V <= 48 ? 48 : 64));      // output columns a thread carries (zero padded)
+    const size_t lds = ((size_t)nsum * V * VP + (size_t)256 * V + 4) * sizeof(float);
+    const dim3 grid(ceil_div(R, 256), batch);
+#define LAUNCH_RM(VPC)                                                                     \
+    do {                                                                                   \
+        STGCN_HIP_CHECK(allow_lds(rowmix_kernel<VPC>, lds));                               \
+        hipLaunchKernelGGL(rowmix_kernel<VPC>, grid, dim3(256), lds, st, a);               \
+    } while (0)
+    if (VP == 24) LAUNCH_RM(24); else if (VP == 32) LAUNCH_RM(32); else if (VP == 48) LAUNCH_RM(48); else LAUNCH_RM(64);
+#undef LAUNCH_RM
+    STGCN_LAUNCH_CHECK("rowmix_kernel");
     return STGCN_OK;
 }
 

@@ -191,7 +191,7 @@ def main():
                     help="timed steps of the tertiary block: training step of the two deeper TCN_GCN_unit shapes (0 = skip; 1 GPU only)")
     ap.add_argument("--no-extras", action="store_true", help="headline block only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=32)
+    ap.add_argument("--cpu-clips", type=int, default=64)
     args = ap.parse_args()
     if args.no_extras:
         args.steady_steps = args.alt_steps = args.train_steps = args.other_steps = args.deeper_steps = 0
@@ -469,7 +469,7 @@ def main():
 
     if rank == 0:
         if cpu_state is not None:
-            line["cpu_baseline"], line["cpu_oracle"] = cpu_legs(*cpu_state, T, V, args.cpu_clips, 5)
+            line["cpu_baseline"], line["cpu_oracle"] = cpu_legs(*cpu_state, T, V, args.cpu_clips, 12)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
